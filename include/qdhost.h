@@ -1,0 +1,63 @@
+/*
+ * qdhost.h -- C-ABI of the host front end (libqdhost.so, plain C++17, no GPU).
+ *
+ * This is the part of the reference that "stays on the host" (SURVEY.md rows
+ * M5, C1, F2 and the asset loaders): it reads a .qdmg scene and its assets and
+ * produces the flat qd_scene_desc that qd_scene_create() uploads.
+ *   .qdmg grammar        : src/scene.cpp:391-612 (DefaultSceneParser::Parse), class table :871-918
+ *   OBJ + triangle data  : src/mesh.cpp:434-540
+ *   mesh bbox + KD build : src/mesh.cpp:99-104, :198-432
+ *   BMP reader / writer  : src/bitmap.cpp:101-220
+ *   EXR (scan-line PIZ)  : src/bitmap.cpp:222-252 (the reference calls OpenEXR 2.0.1; this is a from-scratch reader)
+ *   heightfield prep     : src/heightfield.cpp:102-214, :260-290
+ *   bump differentiate   : src/bitmap.cpp:312-326
+ *   camera corners       : src/camera.cpp:6-24
+ */
+#ifndef QDHOST_H
+#define QDHOST_H
+
+#include "qdtrace.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qdh_scene qdh_scene;  /* owns every array referenced by its qd_scene_desc */
+
+/* Replaces Scene::ParseScene + Scene::BeginRender + Camera::BeginFrame
+ * (src/scene.cpp:803-821, src/camera.cpp:6-24). Returns NULL on error (see qdh_last_error),
+ * like the reference's `false` + message on stderr (src/scene.cpp:579-592). */
+qdh_scene* qdh_load_scene(const char* qdmg_path);
+
+/* Synthetic benchmark scene (BASELINE.json configs[4], SURVEY.md 8(d) input 5):
+ * displaced-grid glass mesh of 2*n*n triangles over a checker floor, one light,
+ * optional cubemap folder (NULL = no environment). */
+qdh_scene* qdh_synth_scene(int n, unsigned seed, int width, int height, int max_trace_depth,
+                           const char* env_folder);
+
+/* The flat description (valid until qdh_free_scene). Mutable on purpose: callers may
+ * override settings (frame size, AA flags, depth) before rendering. */
+qd_scene_desc* qdh_scene_desc(qdh_scene* s);
+
+/* Recompute camera corners after changing camera parameters (Camera::BeginFrame). */
+void qdh_camera_corners(const double position[3], double yaw, double pitch, double roll,
+                        double fov, double aspect, qd_camera* out);
+
+/* Serpentine 48x48 bucket list (GetBucketList, src/sdl.cpp:253-276): writes up to cap rects
+ * as x0,y0,x1,y1 and returns the number of buckets. */
+int qdh_bucket_list(int width, int height, int32_t* rects, int cap);
+
+/* Bitmap::SaveBMP (src/bitmap.cpp:181-220) on a float RGB image, incl. ConvertTo8Bit quantisation. */
+int qdh_save_bmp(const char* path, const float* rgb, int width, int height, size_t row_pitch_floats);
+
+/* Bitmap::LoadImage (BMP / EXR) exposed for tests: returns malloc'd float RGB (free with qdh_free). */
+float* qdh_load_image(const char* path, uint32_t* width, uint32_t* height);
+void   qdh_free(void* p);
+
+void qdh_free_scene(qdh_scene* s);
+const char* qdh_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QDHOST_H */

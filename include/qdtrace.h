@@ -1,0 +1,278 @@
+/*
+ * qdtrace.h -- C-ABI boundary of the MI355X trace path ("Quad Damage" per-pixel
+ * trace path: ray generation -> closest hit (KD-tree mesh / analytic / CSG /
+ * heightfield) -> shading loop with shadow + secondary rays -> float RGB).
+ *
+ * The reference has no FFI layer; the seam this header replaces is the pixel
+ * loop of SimpleRender():
+ *     vfb[y][x] = Raytrace(scene.camera->GetScreenRay(x, y));
+ *     (reference: src/main.cpp:85-104, Raytrace src/main.cpp:18-56,
+ *      Camera::GetScreenRay src/camera.cpp:26-41)
+ * Inputs are the immutable scene *after* Scene::BeginRender() (src/scene.cpp:809-821)
+ * and the camera *after* Camera::BeginFrame() (src/camera.cpp:6-24), flattened
+ * into the plain arrays of qd_scene_desc; the output is the caller-owned
+ * float RGB framebuffer (reference: `Color vfb[1920][1920]`, src/main.cpp:15).
+ *
+ * Everything here is plain C: pointers, sizes, PODs.  No torch / HIP types.
+ * All multi-byte values are little-endian host order; all geometry is FP64,
+ * all colours FP32 (reference: src/vector.h:7-16, src/color.h:29-33).
+ */
+#ifndef QDTRACE_H
+#define QDTRACE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ----------------------------------------------------------------------------
+ * Scene description (host memory, caller-owned; qd_scene_create copies it).
+ * -------------------------------------------------------------------------- */
+
+/* Geometry kinds (reference: class table src/scene.cpp:875-885). */
+enum {
+    QD_GEOM_PLANE       = 0, /* src/geometry.cpp:6-28    p = {y, limit}               */
+    QD_GEOM_SPHERE      = 1, /* src/geometry.cpp:49-87   p = {cx, cy, cz, radius}     */
+    QD_GEOM_CUBE        = 2, /* src/geometry.cpp:107-162 p = {cx, cy, cz, halfSide}   */
+    QD_GEOM_CSG         = 3, /* src/geometry.cpp:184-242 a = left geom, b = right geom, c = op */
+    QD_GEOM_REGPOLY     = 4, /* src/geometry.cpp:259-296 p = {cx, cy, cz, radius}, a = sides */
+    QD_GEOM_MESH        = 5, /* src/mesh.cpp:30-168      a = mesh index               */
+    QD_GEOM_HEIGHTFIELD = 6  /* src/heightfield.cpp:20-77 a = heightfield index       */
+};
+enum { QD_CSG_AND = 0, QD_CSG_PLUS = 1, QD_CSG_MINUS = 2 }; /* src/geometry.h:124-140 */
+
+typedef struct qd_geom {
+    int32_t type;
+    int32_t a, b, c;
+    double  p[4];
+} qd_geom;
+
+/* One scene node: geometry + shader + transform (src/geometry.h:142-156,
+ * src/transform.h:29-33).  Matrices are row-major 3x3, applied as row-vector * M
+ * (src/matrix.cpp:10-17). */
+typedef struct qd_node {
+    int32_t geom;                 /* index into geoms[]                        */
+    int32_t shader;               /* index into shaders[]                      */
+    int32_t bump_tex;             /* index into textures[] or -1               */
+    float   shadow_transparency;  /* src/geometry.h:148                        */
+    double  M[9];                 /* m_Transform                               */
+    double  Minv[9];              /* m_InverseTransform                        */
+    double  MinvT[9];             /* m_TransposedInverse                       */
+    double  offset[3];            /* m_Offset                                  */
+} qd_node;
+
+/* KD-tree node, 16 bytes (reference KDTreeNode is 24 B, src/KDTree.h:8-18).
+ * meta = (index << 2) | axis; axis 0..2 = inner node (index = left child,
+ * right child = index + 1, mirroring `new KDTreeNode[2]`, src/KDTree.cpp:23);
+ * axis 3 = leaf (index = first entry in leaf_tris[], count = entries). */
+typedef struct qd_kdnode {
+    double   split;
+    uint32_t meta;
+    uint32_t count;
+} qd_kdnode;
+
+enum { QD_MESH_FACETED = 1, QD_MESH_BACKCULL = 2 };
+
+typedef struct qd_mesh {
+    uint32_t tri_first;   /* first triangle of this mesh in the global triangle arrays  */
+    uint32_t tri_count;
+    int32_t  kd_root;     /* index into kd_nodes[] or -1 (no tree: < 50 tris or useKDTree false, src/mesh.cpp:200) */
+    uint32_t flags;       /* QD_MESH_*  (src/mesh.h:48-49)                               */
+    double   bbox_min[3]; /* includes the dummy vertex (0,0,0), src/mesh.cpp:516,99-104  */
+    double   bbox_max[3];
+    /* KD build statistics, the values the reference prints at src/mesh.cpp:211-213 */
+    uint32_t kd_max_depth;
+    uint32_t kd_leaves;
+    uint64_t kd_depth_sum;
+    uint64_t kd_leaf_tris;
+} qd_mesh;
+
+/* Heightfield (src/heightfield.h:19-45).  Arrays are row-major [z * width + x]. */
+typedef struct qd_heightfield {
+    uint32_t width, height;
+    int32_t  use_optimization;
+    int32_t  max_k;                /* src/heightfield.cpp:262 */
+    double   bbox_min[3], bbox_max[3];
+    uint64_t heights_off;          /* offsets (in elements) into hf_f32[] */
+    uint64_t maxheights_off;
+    uint64_t highmap_off;          /* 16 floats per cell; valid iff use_optimization */
+    uint64_t normals_off;          /* offset (in doubles) into hf_f64[], 3 per cell   */
+} qd_heightfield;
+
+/* Shaders (src/shading.h, class table src/scene.cpp:888-895). */
+enum {
+    QD_SH_CONST = 0, QD_SH_LAMBERT = 1, QD_SH_PHONG = 2, QD_SH_BLINNPHONG = 3,
+    QD_SH_ORENNAYAR = 4, QD_SH_REFL = 5, QD_SH_REFR = 6, QD_SH_LAYERED = 7
+};
+typedef struct qd_shader {
+    int32_t type;
+    int32_t tex;        /* diffuse texture index or -1                              */
+    float   color[3];
+    int32_t i0;         /* REFL: numSamples; LAYERED: first layer in layers[]       */
+    int32_t i1;         /* LAYERED: number of layers                                */
+    int32_t pad_;
+    double  p0;         /* PHONG: specularMultiplier; ORENNAYAR: sigma; REFL: multiplier; REFR: ior */
+    double  p1;         /* PHONG: specularExponent;  REFL: glossiness; REFR: multiplier             */
+} qd_shader;
+
+typedef struct qd_layer {  /* src/shading.h:131-136 */
+    int32_t shader;
+    int32_t tex;           /* blend texture or -1 */
+    float   blend[3];
+} qd_layer;
+
+/* Textures (src/texture.h, class table src/scene.cpp:898-906). */
+enum {
+    QD_TEX_CONST = 0, QD_TEX_CHECKER = 1, QD_TEX_MANDELBROT = 2, QD_TEX_PROCEDURAL = 3,
+    QD_TEX_BITMAP = 4, QD_TEX_FRESNEL = 5, QD_TEX_BUMPMAP = 6, QD_TEX_BUMPS = 7
+};
+typedef struct qd_texture {
+    int32_t type;
+    int32_t bitmap;      /* BITMAP/BUMPMAP: index into bitmaps[]                      */
+    float   color1[3];
+    float   color2[3];
+    int32_t bilinear;
+    int32_t i0, i1;      /* PROCEDURAL: first line / line count in proc_lines[]       */
+    int32_t pad_;
+    double  scaling;     /* CHECKER/MANDELBROT: scaling; BITMAP/BUMPMAP: 1/scaling (stored inverted, src/texture.cpp:203-204) */
+    double  p0;          /* FRESNEL: ior; BUMPMAP: strength; BUMPS: strength (float value) */
+} qd_texture;
+
+typedef struct qd_proc_line { /* src/texture.h:69-76 */
+    float  color_u[3]; float color_v[3];
+    double freq_u, freq_v;
+} qd_proc_line;
+
+typedef struct qd_bitmap {
+    uint32_t width, height;
+    uint64_t texel_off;  /* offset in float3 texels into texels[] (row-major x + y*w, src/bitmap.cpp:49) */
+} qd_bitmap;
+
+typedef struct qd_light { double pos[3]; double intensity; } qd_light; /* src/light.h:6-13 */
+
+typedef struct qd_camera {      /* Camera after BeginFrame, src/camera.cpp:6-24 */
+    double top_left[3], top_right[3], bottom_left[3], position[3];
+} qd_camera;
+
+typedef struct qd_settings {    /* src/scene.h:228-252 */
+    int32_t  frame_width, frame_height;
+    float    ambient[3];
+    uint32_t max_trace_depth;
+    int32_t  want_aa, want_adaptive_aa, show_aa, use_srgb;
+    float    aa_debug_color[3];
+    int32_t  pad_;
+    double   aa_threshold;
+} qd_settings;
+
+typedef struct qd_scene_desc {
+    qd_settings settings;
+    qd_camera   camera;
+
+    uint32_t n_nodes;      const qd_node*        nodes;     /* file order, shader-less nodes removed (src/scene.cpp:603-610) */
+    uint32_t n_geoms;      const qd_geom*        geoms;
+    uint32_t n_meshes;     const qd_mesh*        meshes;
+    uint32_t n_hfields;    const qd_heightfield* hfields;
+    uint32_t n_shaders;    const qd_shader*      shaders;
+    uint32_t n_layers;     const qd_layer*       layers;
+    uint32_t n_textures;   const qd_texture*     textures;
+    uint32_t n_proc_lines; const qd_proc_line*   proc_lines;
+    uint32_t n_bitmaps;    const qd_bitmap*      bitmaps;
+    uint32_t n_lights;     const qd_light*       lights;
+
+    /* Triangles of all meshes, concatenated (index = mesh.tri_first + local index).
+     * tri_verts: 9 doubles per triangle: A, AB = B - A, AC = C - A (the operands
+     *            the reference forms per test at src/mesh.cpp:118-125).
+     * tri_gnormal: 3 doubles (MeshTriangle::geometryNormal, src/mesh.cpp:477-478).
+     * tri_shade: 21 doubles: nA,nB,nC (9), uvA,uvB,uvC (x,y each: 6), dNdx, dNdy (6). */
+    uint64_t n_tris;
+    const double* tri_verts;
+    const double* tri_gnormal;
+    const double* tri_shade;
+
+    uint64_t n_kd_nodes;   const qd_kdnode* kd_nodes;
+    uint64_t n_leaf_tris;  const uint32_t*  leaf_tris;  /* mesh-local triangle indices */
+
+    uint64_t n_texels;     const float*  texels;        /* 3 floats per texel */
+    uint64_t n_hf_f32;     const float*  hf_f32;
+    uint64_t n_hf_f64;     const double* hf_f64;
+
+    int32_t env_present;     /* CubemapEnvironment (src/environment.h:30-50)            */
+    int32_t env_bilinear;
+    int32_t env_faces[6];    /* bitmap index per face, order negx,negy,negz,posx,posy,posz */
+} qd_scene_desc;
+
+/* ----------------------------------------------------------------------------
+ * Device library entry points (libqdtrace.so, HIP / gfx950).
+ * -------------------------------------------------------------------------- */
+
+typedef struct qd_scene qd_scene;   /* opaque: scene buffers resident in HBM of the current device */
+
+typedef struct qd_stats {
+    uint64_t rays;            /* traced Raytrace calls (depth test passed, src/main.cpp:20) + shadow queries (src/shadinghelper.cpp:20) */
+    uint64_t primary_rays;
+    uint64_t shadow_rays;
+    uint64_t depth_killed;    /* Raytrace calls cut by ray.depth > maxTraceDepth       */
+    uint64_t kd_nodes_visited;/* KD nodes touched (inner + leaf)                        */
+    uint64_t tris_tested;     /* triangle tests after back-face culling (nbTriIntersections, src/mesh.cpp:116) */
+    uint64_t mesh_queries;    /* ray/mesh queries that pass the mesh bbox (nbIntersections, src/mesh.cpp:38)     */
+    double   kernel_ms;       /* device time of the trace kernel(s), HIP events         */
+} qd_stats;
+
+/* Replaces: process start-up (the reference has none for a device). 0 on success, <0 on error.
+ * device = HIP device ordinal to bind this process to (one process per GPU). */
+int qd_init(int device);
+
+/* Replaces: Scene::BeginRender() fan-out as far as the render path is concerned
+ * (src/scene.cpp:809-821): uploads the flattened scene to HBM. The caller keeps
+ * ownership of every pointer in *desc. */
+int qd_scene_create(const qd_scene_desc* desc, qd_scene** out);
+
+/* Replaces: the double loop of SimpleRender() (src/main.cpp:90-97) restricted to the
+ * pixel rectangle [x0,x1) x [y0,y1) of a frame_width x frame_height frame.
+ *   camera/settings : as Scene::BeginFrame() leaves them (src/scene.cpp:823-835)
+ *   rgb             : caller-owned HOST buffer, pixel (x,y) at rgb[(y-y0)*row_pitch_floats + (x-x0)*3]
+ *   hit_node/hit_tri/hit_dist : optional (may be NULL) primary-ray closest hit per pixel,
+ *                     packed (y-y0)*(x1-x0)+(x-x0): node index (-1 = sky), mesh-local
+ *                     triangle index (-1 for non-mesh), world-space distance.
+ *   stats           : optional.
+ * Returns 0, or <0 and sets qd_last_error(). */
+int qd_render(qd_scene* scene, const qd_camera* camera, const qd_settings* settings,
+              int x0, int y0, int x1, int y1,
+              float* rgb, size_t row_pitch_floats,
+              int32_t* hit_node, int32_t* hit_tri, double* hit_dist,
+              qd_stats* stats);
+
+/* Same as qd_render but every output pointer is DEVICE memory and the call only
+ * enqueues work on `hip_stream` (a hipStream_t passed as void*; NULL = default
+ * stream).  Pixels are selected by tile ownership instead of a rectangle:
+ * the frame is cut into tile x tile squares numbered row-major; this call renders
+ * the tiles t with t % tile_stride == tile_phase (multi-GPU sharding,
+ * one process per GPU) and writes them *compacted*: owned tile number k (in
+ * increasing t) occupies rgb_dev[k*tile*tile*3 ...], row-major inside the tile.
+ * Used by bench.py / the RCCL gather path.  stats_dev: optional device qd_stats. */
+int qd_render_tiles_async(qd_scene* scene, const qd_camera* camera, const qd_settings* settings,
+                          int tile, int tile_phase, int tile_stride,
+                          float* rgb_dev, qd_stats* stats_dev, void* hip_stream);
+
+/* De-interleave kernel for the gathered framebuffer: src_dev holds, for each rank r in
+ * [0, tile_stride), that rank's compacted tiles (each rank's block padded to
+ * tiles_per_rank_padded tiles); writes the row-major W x H x 3 image to dst_dev. */
+int qd_untile_async(const float* src_dev, float* dst_dev, int width, int height,
+                    int tile, int tile_stride, int tiles_per_rank_padded, void* hip_stream);
+
+/* Replaces: Color::toRGB32 / ConvertTo8Bit (src/color.cpp:16-24, src/utils.h:22,34):
+ * clamp, floor(x*255+0.5); rgb float image (device) -> packed 8-bit B,G,R rows
+ * bottom-up as Bitmap::SaveBMP writes them (src/bitmap.cpp:209-217). */
+int qd_quantize_bgr8_async(const float* rgb_dev, uint8_t* bgr_dev, int width, int height,
+                           size_t row_bytes, void* hip_stream);
+
+void qd_scene_destroy(qd_scene* scene);
+void qd_shutdown(void);
+const char* qd_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QDTRACE_H */

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Regenerates the "*_fixed" scene files from the reference's shipped .qdmg files
+# (run in the build container only; /root/reference does not exist on the GPU box).
+# Edits: the shipped scenes use class names the reference parser does not
+# know (src/scene.cpp:871-918), so line-initial Reflection->Refl, Refraction->Refr,
+# BumpmapTexture->BumpTexture; wantAA true->false; lecture7: the file-less soccer-ball Mesh and
+# its Node are removed; kdtree_test: the stripped mesh blob is replaced by geometries/1-low.obj
+# (the alternative named in the scene file itself, data/kdtree_test.qdmg:98).
+set -e
+R=${1:-/root/reference/data}
+D=$(dirname "$0")/data
+fix() { sed -e 's/^Reflection /Refl /' -e 's/^Refraction /Refr /' -e 's/^BumpmapTexture /BumpTexture /' \
+            -e 's/^\(\s*wantAA\s\+\)true/\1false/' "$1"; }
+fix $R/window.qdmg      > $D/window_fixed.qdmg
+fix $R/bumpmap.qdmg     > $D/bumpmap_fixed.qdmg
+fix $R/heightfield.qdmg > $D/heightfield_fixed.qdmg
+fix $R/lecture7.qdmg | awk '/^Mesh soccer_ball_geom/{skip=1} /^Node soccer_ball/{skip=1} {if(!skip)print} /^}/{skip=0}' > $D/lecture7_fixed.qdmg
+fix $R/kdtree_test.qdmg | sed -e 's#geometries/Gas-and-oil-pumps_high.obj#geometries/1-low.obj#' > $D/kdtree_fixed.qdmg
+# the two "env removed" KD probes of SURVEY.md section 4 (mesh swapped, CubemapEnvironment block deleted)
+noenv() { awk '/^CubemapEnvironment/{skip=1} {if(!skip)print} /^}/{skip=0}'; }
+fix $R/kdtree_test.qdmg | sed -e 's#geometries/Gas-and-oil-pumps_high.obj#geometries/teapot_lowres.obj#' | noenv > $D/kdtree_teapot_lowres_noenv.qdmg
+fix $R/kdtree_test.qdmg | sed -e 's#geometries/Gas-and-oil-pumps_high.obj#geometries/1-low.obj#' | noenv > $D/kdtree_1low_noenv.qdmg
+fix $R/kdtree_test.qdmg | sed -e 's#geometries/Gas-and-oil-pumps_high.obj#geometries/teapot_hires.obj#' -e 's/^\(\s*useKDTree true\)/\1\n\tuseSAH true/' | noenv > $D/kdtree_teapot_hires_sah_noenv.qdmg
