@@ -1,0 +1,975 @@
+/*
+ * oracle.cpp -- CPU restatement of the reference's per-pixel trace path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it; the product path (raytracing_amd/) never does.
+ *
+ * It restates, recursion-faithfully and in the reference's FP operation order (FP64 geometry,
+ * FP32 colours, no FMA contraction), the functions of SURVEY.md section 8(a); each function below
+ * cites the reference file:line it follows.  Input is the same flat qd_scene_desc the device
+ * library consumes (include/qdtrace.h), so oracle and HIP path see identical scene bytes.
+ *
+ * Parity pin: the reference itself cannot be built in this image without stand-in SDL/OpenEXR
+ * headers (src/mesh.cpp:5, src/main.cpp:2, src/bitmap.cpp:9-11), so the oracle is pinned against
+ * the outputs of the unmodified reference recorded in SURVEY.md sections 4/6/8(c): KD statistics,
+ * per-ray box/triangle test averages, ray counts, spot pixels and whole-frame md5 digests of the
+ * raw float framebuffer (tests/golden/reference_kats.json, tests/test_oracle_kats.py).
+ */
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "oracle.h"
+
+namespace {
+
+const double PI = 3.141592653589793238;   // src/constants.h:10
+const double INF = 1e99;                  // src/constants.h:11
+
+// ------------------------------------------------------------------ math (src/vector.h, src/vector.cpp)
+struct V { double x, y, z; };
+inline V mk(double x, double y, double z) { V v; v.x = x; v.y = y; v.z = z; return v; }
+inline V operator+(const V& a, const V& b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V operator-(const V& a, const V& b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V operator-(const V& a) { return mk(-a.x, -a.y, -a.z); }
+inline V operator*(const V& a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+inline V operator*(double s, const V& a) { return mk(a.x * s, a.y * s, a.z * s); }
+inline V operator/(const V& a, double s) { return mk(a.x / s, a.y / s, a.z / s); }
+inline double dot(const V& a, const V& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                       // src/vector.h:46
+inline V cross(const V& a, const V& b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }  // :57
+inline double len(const V& a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+inline double len_sqr(const V& a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+inline V normalize(V a) { const double m = 1. / len(a); a.x *= m; a.y *= m; a.z *= m; return a; }           // src/vector.h:29
+inline double comp(const V& a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+inline double sqr(double a) { return a * a; }
+inline V ld3(const double* p) { return mk(p[0], p[1], p[2]); }
+inline V mul_mat(const V& v, const double* m) {   // row-vector * 3x3 (src/matrix.cpp:10-17)
+    return mk(v.x * m[0] + v.y * m[3] + v.z * m[6], v.x * m[1] + v.y * m[4] + v.z * m[7], v.x * m[2] + v.y * m[5] + v.z * m[8]);
+}
+inline bool is_between(double x, double lo, double hi, double eps = 1e-6) { return lo - eps <= x && x <= hi + eps; }  // src/utils.h:29
+inline bool is_zero(double a, double eps = 1e-6) { return -eps <= a && a <= eps; }
+inline bool are_equal(double a, double b, double eps = 1e-6) { return is_zero(a - b, eps); }
+inline int sign_of(double x) { return x > 1e-6 ? +1 : (x < -1e-6 ? -1 : 0); }
+
+V reflect(V in, const V& n) {                     // src/vector.cpp:56-62
+    in = normalize(in);
+    in = in - (2 * n) * dot(n, in);
+    return normalize(in);
+}
+V faceforward(const V& ray, const V& n) { return dot(ray, n) < 0 ? n : -n; }   // src/vector.cpp:64-70
+V refract(const V& in, const V& n, double ratio) {                           // src/vector.cpp:72-82
+    const double ndoti = dot(in, n);
+    const double k = 1. - sqr(ratio) * (1. - sqr(ndoti));
+    V r = mk(0, 0, 0);
+    if (k >= 0.) r = ratio * in - (ratio * ndoti + std::sqrt(k)) * n;
+    return r;
+}
+double fresnel_ratio(const V& in, const V& n, double ratio) {                 // src/vector.cpp:84-90
+    const double f = sqr((1. - ratio) / (1 + ratio));
+    return f + (1. - f) * std::pow(1. + dot(in, n), 5.);
+}
+void orthonormal_system(const V& in, V& r1, V& r2) {                          // src/utils.cpp:49-61
+    const V s0 = mk(-0.267261242, 0.534522484, -0.801783726), s1 = mk(+0.483368245, 0.096673649, +0.870062840);
+    r1 = std::fabs(dot(in, s0)) > 0.99 ? cross(in, s1) : cross(in, s0);
+    r1 = normalize(r1);
+    r2 = normalize(cross(in, r1));
+}
+
+// ------------------------------------------------------------------ colours (src/color.h)
+struct Col { float r, g, b; };
+inline Col mkc(float r, float g, float b) { Col c; c.r = r; c.g = g; c.b = b; return c; }
+inline Col operator+(const Col& a, const Col& b) { return mkc(a.r + b.r, a.g + b.g, a.b + b.b); }
+inline Col operator-(const Col& a, const Col& b) { return mkc(a.r - b.r, a.g - b.g, a.b - b.b); }
+inline Col operator*(const Col& a, const Col& b) { return mkc(a.r * b.r, a.g * b.g, a.b * b.b); }
+inline Col operator*(const Col& a, float m) { return mkc(a.r * m, a.g * m, a.b * m); }   // every scalar narrows to float first (:39-40)
+inline Col operator/(const Col& a, float d) { return mkc(a.r / d, a.g / d, a.b / d); }
+inline Col ldc(const float* p) { return mkc(p[0], p[1], p[2]); }
+
+struct Ray { V start, dir; unsigned depth; uint32_t path; };
+
+struct Info {           // IntersectionInfo, src/geometry.h:13-22 (+ triangle index for the hit-ID outputs)
+    V ip, normal;
+    double distance, u, v;
+    V rayDir, dNdx, dNdy;
+    int tri;
+};
+inline Info fresh_info() { Info i; memset(&i, 0, sizeof i); i.tri = -1; return i; }
+
+struct Ctx {            // per-thread state: counters + RNG mode
+    const qd_scene_desc* S;
+    qd_settings st;
+    qd_camera cam;
+    int rng_mode;       // 0 = libc rand() in call order (reference), 1 = path-hashed (device-matching)
+    orc_stats stats;
+};
+
+// ------------------------------------------------------------------ random
+// Reference: Random() = rand() / (double) RAND_MAX (src/utils.h:31).  Device-matching mode replaces the
+// libc stream by a hash of (ray path id, sample index, draw index), same range and resolution.
+inline uint32_t mix32(uint32_t h) { h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16; return h; }
+inline uint32_t path_child(uint32_t parent, uint32_t slot, uint32_t sample) {
+    return mix32(parent ^ mix32(0x9e3779b9U + slot * 0x85ebca6bU + sample * 0xc2b2ae35U));
+}
+inline double random01(Ctx& c, uint32_t path, uint32_t sample, uint32_t draw) {
+    if (c.rng_mode == 0) return rand() / (double)RAND_MAX;
+    const uint32_t h = mix32(path ^ mix32(0x68bc21ebU + sample * 0x02e5be93U + draw * 0x967a889bU));
+    return (h & 0x7fffffffU) / 2147483647.0;
+}
+
+// ------------------------------------------------------------------ bounding boxes (src/bbox.cpp)
+struct Box { V mn, mx; };
+bool box_inside(const Box& b, const V& p) {                  // BBox::IsInside :24-31
+    return is_between(p.x, b.mn.x, b.mx.x) && is_between(p.y, b.mn.y, b.mx.y) && is_between(p.z, b.mn.z, b.mx.z);
+}
+bool box_test(const Box& b, const V& start, const V& dir) {  // BBox::TestIntersect :33-97
+    if (box_inside(b, start)) return true;
+    for (int dim = 0; dim < 3; ++dim) {
+        const double d = comp(dir, dim), s = comp(start, dim), lo = comp(b.mn, dim), hi = comp(b.mx, dim);
+        if (d < 0 && s < lo) continue;
+        if (d > 0 && s > hi) continue;
+        if (is_zero(d, 1e-9)) continue;
+        const double mul = 1. / d;
+        const int u = (dim == 0) ? 1 : 0, v = (dim == 2) ? 1 : 2;
+        double dist = (lo - s) * mul;
+        if (dist < 0) continue;   // max plane deliberately not tested in this case
+        double x = comp(start, u) + comp(dir, u) * dist;
+        if (is_between(x, comp(b.mn, u), comp(b.mx, u), 0)) {
+            const double y = comp(start, v) + comp(dir, v) * dist;
+            if (is_between(y, comp(b.mn, v), comp(b.mx, v), 0)) return true;
+        }
+        dist = (hi - s) * mul;
+        if (dist < 0) continue;
+        x = comp(start, u) + comp(dir, u) * dist;
+        if (is_between(x, comp(b.mn, u), comp(b.mx, u), 0)) {
+            const double y = comp(start, v) + comp(dir, v) * dist;
+            if (is_between(y, comp(b.mn, v), comp(b.mx, v), 0)) return true;
+        }
+    }
+    return false;
+}
+double box_closest(const Box& b, const V& start, const V& dir) {  // BBox::ClosestIntersection :99-137
+    if (box_inside(b, start)) return 0.;
+    double best = INF;
+    for (int dim = 0; dim < 3; ++dim) {
+        const double d = comp(dir, dim), s = comp(start, dim), lo = comp(b.mn, dim), hi = comp(b.mx, dim);
+        if (d < 0 && s < lo) continue;
+        if (d > 0 && s > hi) continue;
+        if (is_zero(d, 1e-9)) continue;
+        const double mul = 1. / d;
+        const double xs[2] = {lo, hi};
+        const int u = (dim == 0) ? 1 : 0, v = (dim == 2) ? 1 : 2;
+        for (int j = 0; j < 2; ++j) {
+            const double dist = (xs[j] - s) * mul;
+            if (dist < 0) continue;
+            const double x = comp(start, u) + comp(dir, u) * dist;
+            if (is_between(x, comp(b.mn, u), comp(b.mx, u), 0)) {
+                const double y = comp(start, v) + comp(dir, v) * dist;
+                if (is_between(y, comp(b.mn, v), comp(b.mx, v), 0)) best = std::min(best, dist);
+            }
+        }
+    }
+    return best;
+}
+
+// ------------------------------------------------------------------ mesh (src/mesh.cpp)
+struct MeshView { const qd_mesh* m; const qd_scene_desc* S; };
+
+// Mesh::Intersect(ray, triangle, info) :111-168
+bool tri_intersect(Ctx& c, const MeshView& mv, uint32_t local, const V& start, const V& dir, Info& out) {
+    const qd_scene_desc* S = mv.S;
+    const size_t t = (size_t)mv.m->tri_first + local;
+    if ((mv.m->flags & QD_MESH_BACKCULL) && dot(dir, ld3(S->tri_gnormal + t * 3)) > 0) return false;
+    c.stats.tri_tests++;
+    const double* tv = S->tri_verts + t * 9;
+    const V A = ld3(tv), AB = ld3(tv + 3), AC = ld3(tv + 6);
+    const V H = start - A;
+    const V mD = -dir;
+    const double dcr = dot(cross(AB, AC), mD);
+    if (std::fabs(dcr) < 1e-12) return false;
+    const double gamma = dot(cross(AB, AC), H) / dcr;
+    if (gamma < 0 || gamma > out.distance) return false;
+    const double l2 = dot(cross(H, AC), mD) / dcr;
+    const double l3 = dot(cross(AB, H), mD) / dcr;
+    if (l2 < 0 || l3 < 0 || l2 + l3 > 1) return false;
+    out.distance = gamma;
+    out.ip = start + dir * gamma;
+    const double* sh = S->tri_shade + t * 21;
+    if (!(mv.m->flags & QD_MESH_FACETED)) {
+        const V nA = ld3(sh), nB = ld3(sh + 3), nC = ld3(sh + 6);
+        out.normal = normalize(nA + l2 * (nB - nA) + l3 * (nC - nA));
+    } else {
+        out.normal = ld3(S->tri_gnormal + t * 3);
+    }
+    const V uvA = mk(sh[9], sh[10], 0), uvB = mk(sh[11], sh[12], 0), uvC = mk(sh[13], sh[14], 0);
+    const V uv = uvA + l2 * (uvB - uvA) + l3 * (uvC - uvA);
+    out.u = uv.x; out.v = uv.y;
+    out.dNdx = ld3(sh + 15); out.dNdy = ld3(sh + 18);
+    out.tri = (int)local;
+    return true;
+}
+
+// Mesh::Intersect(KDTreeNode*, BBox, ray, info) :58-92 -- recursive, children gated by the full box test
+bool kd_intersect(Ctx& c, const MeshView& mv, uint32_t node, const Box& box, const V& start, const V& dir, Info& out) {
+    const qd_kdnode& n = mv.S->kd_nodes[node];
+    const uint32_t axis = n.meta & 3u, idx = n.meta >> 2;
+    c.stats.kd_nodes_visited++;
+    if (axis == 3) {
+        bool found = false;
+        for (uint32_t i = 0; i < n.count; ++i)
+            if (tri_intersect(c, mv, mv.S->leaf_tris[idx + i], start, dir, out)) found = true;
+        return found && box_inside(box, out.ip);
+    }
+    Box child[2] = {box, box};
+    if (axis == 0) { child[0].mx.x = n.split; child[1].mn.x = n.split; }
+    else if (axis == 1) { child[0].mx.y = n.split; child[1].mn.y = n.split; }
+    else { child[0].mx.z = n.split; child[1].mn.z = n.split; }
+    int order[2] = {0, 1};
+    if (comp(start, (int)axis) > n.split) std::swap(order[0], order[1]);
+    for (int i = 0; i < 2; ++i) {
+        c.stats.bbox_tests++;
+        const Box& cb = child[order[i]];
+        if (box_test(cb, start, dir) && kd_intersect(c, mv, idx + order[i], cb, start, dir, out)) return true;
+    }
+    return false;
+}
+
+// Mesh::Intersect(ray, info) :30-56
+bool mesh_intersect(Ctx& c, int mesh, const V& start, const V& dir, Info& out) {
+    const MeshView mv{&c.S->meshes[mesh], c.S};
+    const Box box{ld3(mv.m->bbox_min), ld3(mv.m->bbox_max)};
+    if (!box_test(box, start, dir)) return false;
+    bool found = false;
+    out.distance = INF;
+    if (mv.m->kd_root >= 0) {
+        c.stats.mesh_queries++;
+        found = kd_intersect(c, mv, (uint32_t)mv.m->kd_root, box, start, dir, out);
+    } else {
+        for (uint32_t i = 0; i < mv.m->tri_count; ++i)
+            if (tri_intersect(c, mv, i, start, dir, out)) found = true;
+    }
+    return found;
+}
+
+// IntersectTriangleFast, src/mesh.cpp:542-580
+bool tri_fast(const V& start, const V& dir, const V& A, const V& B, const V& C, double& dist) {
+    const V AB = B - A, AC = C - A, D = -dir, H = start - A;
+    const V n = cross(AB, AC);
+    const double dcr = dot(n, D);
+    if (std::fabs(dcr) < 1e-12) return false;
+    const double gamma = dot(n, H) / dcr;
+    if (gamma < 0 || gamma > dist) return false;
+    const double l2 = dot(cross(H, AC), D) / dcr;
+    const double l3 = dot(cross(AB, H), D) / dcr;
+    if (l2 < 0 || l3 < 0 || l2 + l3 > 1) return false;
+    dist = gamma;
+    return true;
+}
+
+// ------------------------------------------------------------------ heightfield (src/heightfield.cpp)
+struct HfView {
+    const qd_heightfield* h; const float* heights; const float* maxh; const float* highmap; const double* normals;
+    float get_height(int x, int y) const {
+        x = std::min(std::max(x, 0), (int)h->width - 1); y = std::min(std::max(y, 0), (int)h->height - 1);
+        return heights[(size_t)y * h->width + x];
+    }
+    float get_highest(int x, int y, int k) const {
+        x = std::min(std::max(x, 0), (int)h->width - 1); y = std::min(std::max(y, 0), (int)h->height - 1);
+        return highmap[((size_t)y * h->width + x) * 16 + k];
+    }
+    V normal_at(unsigned x, unsigned y) const { return ld3(normals + ((size_t)y * h->width + x) * 3); }
+    V get_normal(float x, float y) const {   // :230-245, float weights
+        unsigned x0 = (unsigned)std::floor(x), y0 = (unsigned)std::floor(y);
+        const float p = x - x0, q = y - y0;
+        x0 = std::min(x0, h->width - 1); y0 = std::min(y0, h->height - 1);   // the reference reads out of bounds at ip.x == W; stay in the table
+        const unsigned x1 = std::min(h->width - 1, x0 + 1), y1 = std::min(h->height - 1, y0 + 1);
+        return normal_at(x0, y0) * ((1 - p) * (1 - q)) + normal_at(x1, y0) * ((p) * (1 - q)) +
+               normal_at(x0, y1) * ((1 - p) * (q)) + normal_at(x1, y1) * ((p) * (q));
+    }
+};
+
+bool hf_intersect(Ctx& c, int hf, const V& start, const V& dir, Info& out) {   // Heightfield::Intersect :20-77
+    const qd_heightfield* h = &c.S->hfields[hf];
+    const HfView hv{h, c.S->hf_f32 + h->heights_off, c.S->hf_f32 + h->maxheights_off, c.S->hf_f32 + h->highmap_off,
+                    c.S->hf_f64 + h->normals_off};
+    const Box box{ld3(h->bbox_min), ld3(h->bbox_max)};
+    const int W = (int)h->width, H = (int)h->height;
+    const V step = dir / (std::sqrt(sqr(dir.x) + sqr(dir.z)));
+    const double dist = box_closest(box, start, dir);
+    const double mx = 1.0 / dir.x, mz = 1.0 / dir.z;
+    V p = start + dir * (dist + 1e-6);
+    while (box_inside(box, p)) {
+        // ComputeNextCoordinates :79-100
+        int x0 = (int)std::floor(p.x), z0 = (int)std::floor(p.z);
+        if (!(x0 < 0 || x0 >= W || z0 < 0 || z0 >= H) && h->use_optimization) {
+            int k = 0;
+            while (k < h->max_k && std::min(p.y, p.y + dir.y * (1 << k)) > hv.get_highest(x0, z0, k)) ++k;
+            --k;
+            if (k >= 0) {
+                p = p + dir * (1 << k);
+                x0 = (int)std::floor(p.x); z0 = (int)std::floor(p.z);
+            }
+        }
+        if (x0 < 0 || x0 >= W || z0 < 0 || z0 >= H) break;
+        const double lx = dir.x > 0 ? (std::ceil(p.x) - p.x) * mx : (std::floor(p.x) - p.x) * mx;
+        const double lz = dir.z > 0 ? (std::ceil(p.z) - p.z) * mz : (std::floor(p.z) - p.z) * mz;
+        const V p_next = p + step * (std::min(lx, lz) + 1e-6);
+        if (std::min(p.y, p_next.y) < hv.maxh[(size_t)z0 * W + x0]) {
+            double closest = INF;
+            const V A = mk(x0, hv.get_height(x0, z0), z0);
+            const V B = mk(x0 + 1, hv.get_height(x0 + 1, z0), z0);
+            const V C = mk(x0 + 1, hv.get_height(x0 + 1, z0 + 1), z0 + 1);
+            const V D = mk(x0, hv.get_height(x0, z0 + 1), z0 + 1);
+            if (tri_fast(start, dir, A, B, D, closest) || tri_fast(start, dir, B, C, D, closest)) {
+                out.distance = closest;
+                out.ip = start + dir * closest;
+                out.normal = hv.get_normal(static_cast<float>(out.ip.x), static_cast<float>(out.ip.z));
+                out.u = out.ip.x / h->width;
+                out.v = out.ip.z / h->height;
+                out.dNdx = mk(1, 0, 0);
+                out.dNdy = mk(0, 0, 1);
+                return true;
+            }
+        }
+        p = p_next;
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------ analytic geometry (src/geometry.cpp)
+bool geom_intersect(Ctx& c, int gi, const V& start, const V& dir, Info& out);
+
+bool plane_intersect(const qd_geom& g, const V& start, const V& dir, Info& out) {   // :6-28
+    const double height = g.p[0], limit = g.p[1];
+    if (start.y > height && dir.y >= 0.) return false;
+    if (start.y < height && dir.y <= 0.) return false;
+    const double sf = (height - start.y) / dir.y;
+    out.ip = start + dir * sf;
+    if (std::abs(out.ip.x) > limit || std::abs(out.ip.z) > limit) return false;
+    out.distance = sf;
+    out.normal = mk(0., start.y > height ? 1. : -1., 0.);
+    out.u = out.ip.x; out.v = out.ip.z;
+    out.dNdx = mk(1, 0, 0); out.dNdy = mk(0, 0, 1);
+    return true;
+}
+
+bool sphere_intersect(const qd_geom& g, const V& start, const V& dir, Info& out) {  // :49-87
+    const V center = mk(g.p[0], g.p[1], g.p[2]);
+    const double R = g.p[3];
+    const V H = start - center;
+    const double A = 1;
+    const double B = 2 * dot(H, dir);
+    const double C = len_sqr(H) - sqr(R);
+    const double discr = sqr(B) - 4 * A * C;
+    if (discr < 0) return false;
+    const double p1 = (-B - std::sqrt(discr)) / (2 * A);
+    const double p2 = (-B + std::sqrt(discr)) / (2 * A);
+    double p;
+    if (p1 > 0) p = p1; else if (p2 > 0) p = p2; else return false;
+    out.distance = p;
+    out.ip = start + dir * p;
+    const V rel = out.ip - center;
+    out.normal = normalize(rel);
+    out.u = std::atan2(rel.z, rel.x);
+    out.u = (out.u + PI) / (2 * PI);
+    out.v = std::asin(rel.y / R);
+    out.v = -(out.v + PI / 2) / PI;
+    return true;   // dNdx / dNdy stay as the caller left them (zero vectors)
+}
+
+bool cube_side(const qd_geom& g, double level, double s, double d, const V& start, const V& dir, const V& normal, Info& out) {  // :107-148
+    const V cn = mk(g.p[0], g.p[1], g.p[2]);
+    const double hs = g.p[3];
+    if (s > level && d >= 0) return false;
+    if (s < level && d <= 0) return false;
+    const double sf = (level - s) / d;
+    const V ip = start + dir * sf;
+    if (ip.y > cn.y + hs + 1e-6) return false;
+    if (ip.y < cn.y - hs - 1e-6) return false;
+    if (ip.x > cn.x + hs + 1e-6) return false;
+    if (ip.x < cn.x - hs - 1e-6) return false;
+    if (ip.z > cn.z + hs + 1e-6) return false;
+    if (ip.z < cn.z - hs - 1e-6) return false;
+    if (out.distance <= sf) return false;
+    out.ip = ip; out.distance = sf; out.normal = normal;
+    if (normal.y == 0) { out.u = out.ip.x + out.ip.z; out.v = out.ip.y; }
+    else { out.u = out.ip.x; out.v = out.ip.z; }
+    return true;
+}
+
+bool cube_intersect(const qd_geom& g, const V& start, const V& dir, Info& out) {    // :150-162
+    const V cn = mk(g.p[0], g.p[1], g.p[2]);
+    const double hs = g.p[3];
+    out.distance = INF;
+    cube_side(g, cn.x - hs, start.x, dir.x, start, dir, mk(-1, 0, 0), out);
+    cube_side(g, cn.x + hs, start.x, dir.x, start, dir, mk(+1, 0, 0), out);
+    cube_side(g, cn.y - hs, start.y, dir.y, start, dir, mk(0, -1, 0), out);
+    cube_side(g, cn.y + hs, start.y, dir.y, start, dir, mk(0, +1, 0), out);
+    cube_side(g, cn.z - hs, start.z, dir.z, start, dir, mk(0, 0, -1), out);
+    cube_side(g, cn.z + hs, start.z, dir.z, start, dir, mk(0, 0, +1), out);
+    return out.distance < INF;
+}
+
+bool regpoly_intersect(const qd_geom& g, const V& start, const V& dir, Info& out) { // :259-296
+    const V cn = mk(g.p[0], g.p[1], g.p[2]);
+    const double R = g.p[3];
+    const unsigned sides = (unsigned)g.a;
+    if (start.y > cn.y && dir.y >= 0.) return false;
+    if (start.y < cn.y && dir.y <= 0.) return false;
+    const double sf = (cn.y - start.y) / dir.y;
+    const V ip = start + dir * sf;
+    const V d = ip - cn;
+    double angle = std::atan2(d.z, d.x);
+    if (angle < 0) angle += 2 * PI;
+    const double side_angle = 2 * PI / sides;
+    const unsigned k1 = (unsigned)(angle / side_angle);
+    const unsigned k2 = (k1 + 1 == sides ? 0 : k1 + 1);
+    const V vk1 = mk(cn.x + std::cos(k1 * side_angle) * R, cn.y, cn.z + std::sin(k1 * side_angle) * R);
+    const V vk2 = mk(cn.x + std::cos(k2 * side_angle) * R, cn.y, cn.z + std::sin(k2 * side_angle) * R);
+    auto cross_scalar = [](const V& l, const V& r) { return l.x * r.y + l.y * r.z + l.z * r.x - l.x * r.z - l.y * r.x - l.z * r.y; };  // src/vector.h:47
+    const int s1 = sign_of(cross_scalar(vk1 - cn, ip - vk1));
+    const int s2 = sign_of(cross_scalar(vk2 - vk1, ip - vk2));
+    const int s3 = sign_of(cross_scalar(cn - vk2, ip - cn));
+    if (!((s1 >= 0 && s2 >= 0 && s3 >= 0) || (s1 <= 0 && s2 <= 0 && s3 <= 0))) return false;
+    out.ip = ip; out.distance = sf;
+    out.normal = mk(0., start.y > cn.y ? 1. : -1., 0.);
+    out.u = ip.x - cn.x; out.v = ip.z - cn.z;
+    return true;
+}
+
+bool geom_inside(const qd_scene_desc* S, int gi, const V& p) {   // IsInside overrides
+    const qd_geom& g = S->geoms[gi];
+    switch (g.type) {
+        case QD_GEOM_PLANE: return p.y == g.p[0];                                             // :30-35
+        case QD_GEOM_SPHERE: return len_sqr(p - mk(g.p[0], g.p[1], g.p[2])) <= sqr(g.p[3]);  // :89-93
+        case QD_GEOM_CUBE: {                                                                  // :164-170
+            bool r = are_equal(p.x, g.p[0], g.p[3]);
+            r &= are_equal(p.y, g.p[1], g.p[3]);
+            r &= are_equal(p.z, g.p[2], g.p[3]);
+            return r;
+        }
+        case QD_GEOM_REGPOLY: return p.y == g.p[1];                                           // :298-303
+        case QD_GEOM_CSG: {                                                                   // :236-242
+            const bool a = geom_inside(S, g.a, p), b = geom_inside(S, g.b, p);
+            return g.c == QD_CSG_AND ? (a && b) : (g.c == QD_CSG_PLUS ? (a || b) : (a && !b));
+        }
+        default: return false;   // Mesh (src/mesh.cpp:94-97), Heightfield (src/heightfield.h:14)
+    }
+}
+
+inline bool csg_op(int op, bool a, bool b) { return op == QD_CSG_AND ? (a && b) : (op == QD_CSG_PLUS ? (a || b) : (a && !b)); }
+
+bool csg_intersect(Ctx& c, const qd_geom& g, const V& start, const V& dir, Info& out) {   // CsgOp::Intersect :184-234
+    Info li = fresh_info(), ri = fresh_info();
+    bool inA = geom_inside(c.S, g.a, start), inB = geom_inside(c.S, g.b, start);
+    const bool cur = csg_op(g.c, inA, inB);
+    bool lhit = geom_intersect(c, g.a, start, dir, li);
+    bool rhit = geom_intersect(c, g.b, start, dir, ri);
+    while (lhit || rhit) {
+        if (lhit && (!rhit || li.distance <= ri.distance)) {
+            inA = !inA;
+            if (csg_op(g.c, inA, inB) != cur) { out = li; return true; }
+            const double prev = li.distance;
+            lhit = geom_intersect(c, g.a, li.ip + dir * 1e-6, dir, li);
+            if (lhit) li.distance += prev + 1e-6;
+        } else if (rhit && (!lhit || ri.distance <= li.distance)) {
+            inB = !inB;
+            if (csg_op(g.c, inA, inB) != cur) { out = ri; return true; }
+            const double prev = ri.distance;
+            rhit = geom_intersect(c, g.b, ri.ip + dir * 1e-6, dir, ri);
+            if (rhit) ri.distance += prev + 1e-6;
+        }
+    }
+    return false;
+}
+
+bool geom_intersect(Ctx& c, int gi, const V& start, const V& dir, Info& out) {
+    const qd_geom& g = c.S->geoms[gi];
+    switch (g.type) {
+        case QD_GEOM_PLANE: return plane_intersect(g, start, dir, out);
+        case QD_GEOM_SPHERE: return sphere_intersect(g, start, dir, out);
+        case QD_GEOM_CUBE: return cube_intersect(g, start, dir, out);
+        case QD_GEOM_CSG: return csg_intersect(c, g, start, dir, out);
+        case QD_GEOM_REGPOLY: return regpoly_intersect(g, start, dir, out);
+        case QD_GEOM_MESH: return mesh_intersect(c, g.a, start, dir, out);
+        case QD_GEOM_HEIGHTFIELD: return hf_intersect(c, g.a, start, dir, out);
+    }
+    return false;
+}
+
+// Node::Intersect, src/geometry.cpp:319-339 (+ Transform, src/transform.cpp:44-73)
+bool node_intersect(Ctx& c, const qd_node& n, const V& start, const V& dir, Info& out) {
+    const V s = mul_mat(start - ld3(n.offset), n.Minv);
+    V d = mul_mat(dir, n.Minv);
+    const double dl = len(d);
+    d = normalize(d);
+    if (!geom_intersect(c, n.geom, s, d, out)) return false;
+    out.normal = normalize(mul_mat(out.normal, n.MinvT));
+    out.dNdx = normalize(mul_mat(out.dNdx, n.M));
+    out.dNdy = normalize(mul_mat(out.dNdy, n.M));
+    out.ip = mul_mat(out.ip, n.M) + ld3(n.offset);
+    out.distance /= dl;
+    return true;
+}
+
+// ------------------------------------------------------------------ textures (src/texture.cpp, src/bitmap.cpp)
+Col bmp_pixel(const qd_scene_desc* S, const qd_bitmap& b, unsigned x, unsigned y) {   // Bitmap::GetPixel :44-50
+    if (b.width == 0 || x >= b.width || y >= b.height) return mkc(0, 0, 0);
+    return ldc(S->texels + (b.texel_off + x + (size_t)y * b.width) * 3);
+}
+Col bmp_bilinear(const qd_scene_desc* S, const qd_bitmap& b, double x, double y) {    // GetBilinearFilteredPixel :293-310
+    const unsigned xx = static_cast<unsigned>(std::floor(x)), yy = static_cast<unsigned>(std::floor(y));
+    const double p = x - xx, q = y - yy;
+    const unsigned w = b.width, h = b.height;
+    const Col center = bmp_pixel(S, b, xx, yy);
+    const Col right = bmp_pixel(S, b, w ? (xx + 1) % w : 0, yy);
+    const Col down = bmp_pixel(S, b, xx, h ? (yy + 1) % h : 0);
+    const Col dr = bmp_pixel(S, b, w ? (xx + 1) % w : 0, h ? (yy + 1) % h : 0);
+    return center * (float)(1 - p) * (float)(1 - q) + right * (float)p * (float)(1 - q) + down * (float)(1 - p) * (float)q + dr * (float)p * (float)q;
+}
+Col bitmap_helper_color(const qd_scene_desc* S, const qd_texture& t, double u, double v) {   // BitmapHelper::GetColor/GetCoords :139-199
+    const qd_bitmap& b = S->bitmaps[t.bitmap];
+    const unsigned width = b.width, height = b.height;
+    if (width == 0 || height == 0) return mkc(0, 0, 0);
+    if (t.bilinear) {
+        double x = u * t.scaling * width, y = v * t.scaling * height;
+        int xx = static_cast<int>(std::floor(x)), yy = static_cast<int>(std::floor(y));
+        const double dx = x - xx, dy = y - yy;
+        xx = (int)((unsigned)xx % width);     // int %= unsigned: modulo of the two's-complement value
+        yy = (int)((unsigned)yy % height);
+        x = static_cast<double>(xx) + dx; y = static_cast<double>(yy) + dy;
+        return bmp_bilinear(S, b, x, y);
+    }
+    int x = static_cast<int>(std::floor(u * t.scaling * width));
+    int y = static_cast<int>(std::floor(v * t.scaling * height));
+    x = (int)((unsigned)x % width);
+    y = (int)((unsigned)y % height);
+    return bmp_pixel(S, b, (unsigned)x, (unsigned)y);
+}
+
+Col tex_sample(const qd_scene_desc* S, int ti, const Info& info) {
+    const qd_texture& t = S->textures[ti];
+    switch (t.type) {
+        case QD_TEX_CONST: return ldc(t.color1);
+        case QD_TEX_CHECKER: {                                   // :7-14
+            const int x = (int)std::floor(info.u * t.scaling / 5.), y = (int)std::floor(info.v * t.scaling / 5.);
+            return ((x + y) % 2 == 0) ? ldc(t.color1) : ldc(t.color2);
+        }
+        case QD_TEX_MANDELBROT: {                                // :30-59
+            const double x0 = info.u / t.scaling, y0 = info.v / t.scaling;
+            double x = 0, y = 0; unsigned i;
+            for (i = 0; i < 128 && sqr(x) + sqr(y) < 4; ++i) { const double tmp = sqr(x) - sqr(y) + x0; y = 2 * x * y + y0; x = tmp; }
+            const Col c1 = ldc(t.color1), c2 = ldc(t.color2);
+            if (i == 0) return c1;
+            if (i < 16) return c1 * 0.75f + c2 * 0.25f;
+            if (i < 32) return c1 * 0.5f + c2 * 0.5f;
+            if (i < 64) return c1 * 0.25f + c2 * 0.75f;
+            return c2;
+        }
+        case QD_TEX_PROCEDURAL: {                                // :75-82
+            Col r = mkc(0, 0, 0);
+            for (int i = 0; i < t.i1; ++i) {
+                const qd_proc_line& l = S->proc_lines[t.i0 + i];
+                r = r + (ldc(l.color_u) * (float)std::sin(info.u * l.freq_u) + ldc(l.color_v) * (float)std::sin(info.v * l.freq_v));
+            }
+            return r;
+        }
+        case QD_TEX_BITMAP: return bitmap_helper_color(S, t, info.u, info.v);   // :222-226
+        case QD_TEX_FRESNEL: {                                   // :238-249
+            double f;
+            if (dot(info.normal, info.rayDir) > 0) f = fresnel_ratio(info.rayDir, -info.normal, 1. / t.p0);
+            else f = fresnel_ratio(info.rayDir, info.normal, t.p0);
+            const float ff = static_cast<float>(f);
+            return mkc(ff, ff, ff);
+        }
+        default: return mkc(0, 0, 0);   // BumpmapTexture / BumpsTexture sample black (src/texture.h:118,143)
+    }
+}
+
+void tex_modify_normal(const qd_scene_desc* S, int ti, Info& info) {
+    const qd_texture& t = S->textures[ti];
+    if (t.type == QD_TEX_BUMPMAP) {                              // :267-274
+        const Col bump = bitmap_helper_color(S, t, info.u, info.v);
+        const float dx = bump.r, dy = bump.g;
+        info.normal = info.normal + (info.dNdx * dx + info.dNdy * dy) * t.p0;
+        info.normal = normalize(info.normal);
+    } else if (t.type == QD_TEX_BUMPS) {                         // :276-296
+        const float strength = (float)t.p0;
+        if (strength <= 0.f) return;
+        const float freqX[] = {0.5f, 1.21f, 1.9f}, freqZ[] = {0.4f, 1.13f, 1.81f};
+        const float fm = 0.2f;
+        const float intensity[] = {0.1f, 0.08f, 0.05f};
+        double dx = 0, dy = 0;
+        for (unsigned i = 0; i < 3; ++i) {
+            dx += std::sin(fm * freqX[i] * info.u) * intensity[i] * strength;
+            dy += std::sin(fm * freqZ[i] * info.v) * intensity[i] * strength;
+        }
+        info.normal = info.normal + (dx * info.dNdx + dy * info.dNdy);
+        info.normal = normalize(info.normal);
+    }
+}
+
+// ------------------------------------------------------------------ environment (src/environment.cpp:58-108)
+Col env_side(const qd_scene_desc* S, int face, double x, double y) {
+    const qd_bitmap& b = S->bitmaps[S->env_faces[face]];
+    const double nx = (x + 1) * 0.5 * (b.width - 1);
+    const double ny = (y + 1) * 0.5 * (b.height - 1);
+    return S->env_bilinear ? bmp_bilinear(S, b, nx, ny) : bmp_pixel(S, b, static_cast<unsigned>(nx), static_cast<unsigned>(ny));
+}
+Col env_lookup(const qd_scene_desc* S, const V& vec) {
+    double mv = std::abs(vec.x); int md = 0;                    // Vector::MaxDimension, src/vector.cpp:31-47
+    if (std::abs(vec.y) > mv) { mv = std::abs(vec.y); md = 1; }
+    if (std::abs(vec.z) > mv) { mv = std::abs(vec.z); md = 2; }
+    const V t = vec / std::abs(comp(vec, md));
+    const int state = ((comp(t, md) < 0) ? 0 : 3) + md;
+    switch (state) {   // face order negx, negy, negz, posx, posy, posz
+        case 0: return env_side(S, 0, t.z, -t.y);
+        case 1: return env_side(S, 1, t.x, -t.z);
+        case 2: return env_side(S, 2, t.x, t.y);
+        case 3: return env_side(S, 3, -t.z, -t.y);
+        case 4: return env_side(S, 4, t.x, t.z);
+        case 5: return env_side(S, 5, t.x, -t.y);
+    }
+    return mkc(0, 0, 0);
+}
+
+// ------------------------------------------------------------------ shading (src/shading.cpp, src/shadinghelper.cpp)
+Col raytrace(Ctx& c, const Ray& ray);
+
+float shadow_transparency(Ctx& c, const V& start, const V& end) {   // GetShadowTransparency :20-40
+    const V dir = normalize(end - start);
+    const double target = len_sqr(end - start);
+    c.stats.shadow_queries++;
+    float result = 1.f;
+    for (uint32_t i = 0; i < c.S->n_nodes; ++i) {
+        Info info = fresh_info();
+        if (!node_intersect(c, c.S->nodes[i], start, dir, info)) continue;
+        if (sqr(info.distance) < target) result *= c.S->nodes[i].shadow_transparency;
+    }
+    return result;
+}
+double light_contribution(Ctx& c, const Info& info, const qd_light& l) {   // GetLightContribution :11-18
+    const V start = info.ip + info.normal * 1e-6;
+    const float st = shadow_transparency(c, start, ld3(l.pos));
+    const double d2 = len_sqr(info.ip - ld3(l.pos));
+    return st * l.intensity / d2;
+}
+
+Col shade(Ctx& c, int si, const Ray& ray, const Info& info, uint32_t slot);
+
+Col shade_diffuse_family(Ctx& c, const qd_shader& s, const Ray& ray, const Info& info) {
+    const Col diffuse = s.tex >= 0 ? tex_sample(c.S, s.tex, info) : ldc(s.color);
+    Col result = diffuse * ldc(c.st.ambient);
+    if (s.type == QD_SH_ORENNAYAR) {                                         // :102-126
+        const double sigma2 = sqr(s.p0);
+        const double VdotN = dot(-ray.dir, info.normal);
+        for (uint32_t i = 0; i < c.S->n_lights; ++i) {
+            const qd_light& L = c.S->lights[i];
+            const V lightDir = normalize(ld3(L.pos) - info.ip);
+            const double LdotV = dot(lightDir, -ray.dir);
+            const double LdotN = dot(lightDir, info.normal);
+            const double sv = LdotV - LdotN * VdotN;
+            const double t = (sv <= 0. ? 1. : std::max(LdotN, VdotN));
+            const double a = 1 - 0.5 * sigma2 / (sigma2 + 0.33);
+            const double b = 0.45 * sigma2 / (sigma2 + 0.09);
+            const double coeff = LdotN * (a + b * sv / t);
+            const double contrib = light_contribution(c, info, L);
+            result = result + diffuse * (float)coeff * (float)contrib;
+        }
+        return result;
+    }
+    for (uint32_t i = 0; i < c.S->n_lights; ++i) {                           // Lambert :10-25, Phong :52-69
+        const qd_light& L = c.S->lights[i];
+        const V lightDir = normalize(info.ip - ld3(L.pos));
+        const V normal = faceforward(lightDir, info.normal);
+        const double lambert = dot(normal, -lightDir);
+        const double contrib = light_contribution(c, info, L);
+        if (s.type == QD_SH_LAMBERT) {
+            result = result + diffuse * (float)lambert * (float)contrib;
+        } else {
+            double spec;
+            if (s.type == QD_SH_PHONG) {                                     // GetSpecularCoeff :42-50
+                const V refl = reflect(lightDir, normal);
+                const double cg = dot(-ray.dir, refl);
+                spec = cg > 0. ? std::pow(cg, s.p1) : 0.;
+            } else {                                                         // BlinnPhong :93-100
+                const V ld = normalize(ld3(L.pos) - info.ip);
+                const V half = normalize(ld - ray.dir);
+                const double d = dot(info.normal, half);
+                spec = std::pow(std::max(d, 0.), s.p1);
+            }
+            result = result + (diffuse * (float)lambert * (float)contrib +
+                               mkc(1.f, 1.f, 1.f) * (float)spec * (float)s.p0 * (float)contrib);
+        }
+    }
+    return result;
+}
+
+Col shade(Ctx& c, int si, const Ray& ray, const Info& info, uint32_t slot) {
+    const qd_shader& s = c.S->shaders[si];
+    switch (s.type) {
+        case QD_SH_CONST: return ldc(s.color);
+        case QD_SH_LAMBERT: case QD_SH_PHONG: case QD_SH_BLINNPHONG: case QD_SH_ORENNAYAR:
+            return shade_diffuse_family(c, s, ray, info);
+        case QD_SH_REFL: {                                                   // Reflection::Shade :155-198
+            const V n = faceforward(ray.dir, info.normal);
+            Col result = mkc(0, 0, 0);
+            if (s.p1 == 1) {
+                Ray nr = ray;
+                nr.start = info.ip + n * 0.000001;
+                nr.dir = reflect(ray.dir, n);
+                nr.depth++;
+                nr.path = path_child(ray.path, slot, 0);
+                result = raytrace(c, nr) * (float)s.p0;
+            } else {
+                const int count = ray.depth > 0 ? 2 : s.i0;
+                for (int i = 0; i < count; ++i) {
+                    V a, b;
+                    orthonormal_system(n, a, b);
+                    const double angle = random01(c, ray.path, slot * 64u + (uint32_t)i, 0) * 2 * PI;   // GenerateDiscPoint, src/utils.cpp:63-69
+                    const double radius = std::sqrt(random01(c, ray.path, slot * 64u + (uint32_t)i, 1));
+                    double x = std::cos(angle) * radius, y = std::sin(angle) * radius;
+                    const double k = std::tan((1 - s.p1) * PI / 2);
+                    x *= k; y *= k;
+                    const V mn = n + a * x + b * y;
+                    Ray nr = ray;
+                    nr.start = info.ip + n * 0.000001;
+                    nr.dir = reflect(ray.dir, mn);
+                    nr.depth++;
+                    nr.path = path_child(ray.path, slot, (uint32_t)i + 1);
+                    result = result + raytrace(c, nr) * (float)s.p0;
+                }
+                result = result / (float)count;
+            }
+            return result;
+        }
+        case QD_SH_REFR: {                                                   // Refraction::Shade :213-238
+            V refr;
+            if (dot(ray.dir, info.normal) < 0.) refr = refract(ray.dir, info.normal, 1 / s.p0);
+            else refr = refract(ray.dir, -info.normal, s.p0);
+            if (len_sqr(refr) == 0) return mkc(1, 0, 0);   // total internal reflection: pure red
+            Ray nr = ray;
+            nr.start = info.ip - faceforward(ray.dir, info.normal) * 0.000001;
+            nr.dir = refr;
+            nr.depth++;
+            nr.path = path_child(ray.path, slot, 0);
+            return raytrace(c, nr) * (float)s.p1;
+        }
+        case QD_SH_LAYERED: {                                                // Layered::Shade :260-275
+            Col result = mkc(0, 0, 0);
+            for (int i = 0; i < s.i1; ++i) {
+                const qd_layer& l = c.S->layers[s.i0 + i];
+                const Col from = shade(c, l.shader, ray, info, slot * 32u + (uint32_t)i + 1);
+                Col blend = ldc(l.blend);
+                if (l.tex >= 0) blend = blend * tex_sample(c.S, l.tex, info);
+                result = blend * from + (mkc(1, 1, 1) - blend) * result;
+            }
+            return result;
+        }
+    }
+    return mkc(0, 0, 0);
+}
+
+// closest hit over all nodes, file order, strict '<' (src/main.cpp:23-38)
+int closest_node(Ctx& c, const V& start, const V& dir, Info& best) {
+    int node = -1;
+    double dist = INF;
+    best = fresh_info();
+    for (uint32_t i = 0; i < c.S->n_nodes; ++i) {
+        Info info = fresh_info();
+        if (!node_intersect(c, c.S->nodes[i], start, dir, info)) continue;
+        if (dist <= info.distance) continue;
+        dist = info.distance; node = (int)i; best = info;
+    }
+    return node;
+}
+
+Col raytrace(Ctx& c, const Ray& ray) {                                       // Raytrace, src/main.cpp:18-56
+    c.stats.raytrace_calls++;
+    if (ray.depth > c.st.max_trace_depth) { c.stats.depth_killed++; return mkc(0, 0, 0); }
+    Info info;
+    const int node = closest_node(c, ray.start, ray.dir, info);
+    if (node >= 0) {
+        info.rayDir = ray.dir;
+        const qd_node& n = c.S->nodes[node];
+        if (n.bump_tex >= 0) tex_modify_normal(c.S, n.bump_tex, info);
+        return shade(c, n.shader, ray, info, 0);
+    }
+    if (c.S->env_present) return env_lookup(c.S, ray.dir);
+    return mkc(0, 0, 0);
+}
+
+Ray screen_ray(const Ctx& c, double x, double y) {                           // Camera::GetScreenRay, src/camera.cpp:26-41
+    const V TL = ld3(c.cam.top_left), TR = ld3(c.cam.top_right), BL = ld3(c.cam.bottom_left), pos = ld3(c.cam.position);
+    const V through = TL + (TR - TL) * (x / c.st.frame_width) + (BL - TL) * (y / c.st.frame_height);
+    Ray r; r.start = pos; r.dir = normalize(through - pos); r.depth = 0; r.path = 0;
+    return r;
+}
+
+inline uint32_t pixel_path(int x, int y, int sub) { return mix32((uint32_t)x * 0x9e3779b1U ^ mix32((uint32_t)y * 0x85ebca77U + (uint32_t)sub)); }
+
+void add_stats(orc_stats& a, const orc_stats& b) {
+    a.raytrace_calls += b.raytrace_calls; a.depth_killed += b.depth_killed; a.shadow_queries += b.shadow_queries;
+    a.mesh_queries += b.mesh_queries; a.bbox_tests += b.bbox_tests; a.tri_tests += b.tri_tests; a.kd_nodes_visited += b.kd_nodes_visited;
+}
+
+Ctx make_ctx(const qd_scene_desc* S, const qd_camera* cam, const qd_settings* st, int rng_mode) {
+    Ctx c; c.S = S; c.st = st ? *st : S->settings; c.cam = cam ? *cam : S->camera; c.rng_mode = rng_mode;
+    memset(&c.stats, 0, sizeof c.stats);
+    return c;
+}
+
+void trace_pixel(Ctx& c, int x, int y, float* rgb, int32_t* hn, int32_t* ht, double* hd) {
+    Ray ray = screen_ray(c, x, y);
+    ray.path = pixel_path(x, y, 0);
+    const Col col = raytrace(c, ray);
+    rgb[0] = col.r; rgb[1] = col.g; rgb[2] = col.b;
+    if (hn || ht || hd) {
+        Ctx quiet = c; memset(&quiet.stats, 0, sizeof quiet.stats);
+        Info info;
+        const int node = closest_node(quiet, ray.start, ray.dir, info);
+        if (hn) *hn = node;
+        if (ht) *ht = node >= 0 ? info.tri : -1;
+        if (hd) *hd = node >= 0 ? info.distance : 0.;
+    }
+}
+
+}  // namespace
+
+extern "C" int orc_render_rect(const qd_scene_desc* S, const qd_camera* cam, const qd_settings* st,
+                               int x0, int y0, int x1, int y1, float* rgb, size_t pitch,
+                               int32_t* hit_node, int32_t* hit_tri, double* hit_dist,
+                               int rng_mode, int threads, orc_stats* stats) {
+    if (!S || !rgb || x1 < x0 || y1 < y0) return -1;
+    const int w = x1 - x0, h = y1 - y0;
+    if (rng_mode == 0) threads = 1;   // libc rand() order is only defined single-threaded
+    threads = std::max(1, threads);
+    std::atomic<int> next_row(0);
+    std::vector<orc_stats> per(threads);
+    auto work = [&](int tid) {
+        Ctx c = make_ctx(S, cam, st, rng_mode);
+        for (;;) {
+            const int row = next_row.fetch_add(1);
+            if (row >= h) break;
+            for (int i = 0; i < w; ++i) {
+                const size_t k = (size_t)row * w + i;
+                trace_pixel(c, x0 + i, y0 + row, rgb + (size_t)row * pitch + (size_t)i * 3,
+                            hit_node ? hit_node + k : nullptr, hit_tri ? hit_tri + k : nullptr, hit_dist ? hit_dist + k : nullptr);
+            }
+        }
+        per[tid] = c.stats;
+    };
+    if (threads == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t) pool.emplace_back(work, t);
+        for (auto& t : pool) t.join();
+    }
+    if (stats) { memset(stats, 0, sizeof *stats); for (const orc_stats& s : per) add_stats(*stats, s); }
+    return 0;
+}
+
+extern "C" int orc_render_pixels(const qd_scene_desc* S, const qd_camera* cam, const qd_settings* st,
+                                 size_t n, const int32_t* xy, float* rgb,
+                                 int32_t* hit_node, int32_t* hit_tri, double* hit_dist,
+                                 int rng_mode, int threads, orc_stats* stats) {
+    if (!S || !rgb || !xy) return -1;
+    if (rng_mode == 0) threads = 1;
+    threads = std::max(1, threads);
+    std::atomic<size_t> next(0);
+    std::vector<orc_stats> per(threads);
+    auto work = [&](int tid) {
+        Ctx c = make_ctx(S, cam, st, rng_mode);
+        for (;;) {
+            const size_t b = next.fetch_add(64);
+            if (b >= n) break;
+            for (size_t k = b; k < std::min(n, b + 64); ++k)
+                trace_pixel(c, xy[k * 2], xy[k * 2 + 1], rgb + k * 3, hit_node ? hit_node + k : nullptr,
+                            hit_tri ? hit_tri + k : nullptr, hit_dist ? hit_dist + k : nullptr);
+        }
+        per[tid] = c.stats;
+    };
+    if (threads == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t) pool.emplace_back(work, t);
+        for (auto& t : pool) t.join();
+    }
+    if (stats) { memset(stats, 0, sizeof *stats); for (const orc_stats& s : per) add_stats(*stats, s); }
+    return 0;
+}
+
+// Render() = SimpleRender() + AARender() in bucket order on one thread, exactly like the reference
+// (src/main.cpp:58-161, bucket list src/sdl.cpp:253-276).  The framebuffer emulates the static
+// vfb[1920][1920]: neighbours outside the frame but inside 1920 read as black.
+extern "C" int orc_render_frame(const qd_scene_desc* S, float* rgb, int rng_mode, orc_stats* stats) {
+    if (!S || !rgb) return -1;
+    Ctx c = make_ctx(S, nullptr, nullptr, rng_mode);
+    const int W = c.st.frame_width, H = c.st.frame_height;
+    const int VFB = 1920;
+    if (W <= 0 || H <= 0) return -1;
+    if (rng_mode == 0) srand(1);   // a fresh process' libc state
+    std::vector<int> buckets;
+    {
+        const int bs = 48, bw = (W - 1) / bs + 1, bh = (H - 1) / bs + 1;
+        for (int y = 0; y < bh; ++y) {
+            if (y % 2 == 0) for (int x = 0; x < bw; ++x) { buckets.push_back(x); buckets.push_back(y); }
+            else for (int x = bw - 1; x >= 0; --x) { buckets.push_back(x); buckets.push_back(y); }
+        }
+    }
+    auto px = [&](int x, int y) { return rgb + ((size_t)y * W + x) * 3; };
+    for (size_t b = 0; b < buckets.size(); b += 2) {
+        const int bx0 = buckets[b] * 48, by0 = buckets[b + 1] * 48, bx1 = std::min(bx0 + 48, W), by1 = std::min(by0 + 48, H);
+        for (int y = by0; y < by1; ++y)
+            for (int x = bx0; x < bx1; ++x) trace_pixel(c, x, y, px(x, y), nullptr, nullptr, nullptr);
+    }
+    if (c.st.want_aa) {
+        const double kernel[5][2] = {{0.0, 0.0}, {0.6, 0.0}, {0.0, 0.6}, {0.3, 0.3}, {0.6, 0.6}};
+        auto too_different = [&](int x, int y) {   // IsTooDifferent :58-83
+            const int dx[] = {0, 0, -1, 1, -1, -1, 1, 1}, dy[] = {1, -1, 0, 0, -1, 1, 1, -1};
+            for (int i = 0; i < 8; ++i) {
+                const unsigned nx = (unsigned)x + dx[i], ny = (unsigned)y + dy[i];
+                if ((unsigned)VFB <= nx || (unsigned)VFB <= ny) continue;
+                double diff = 0;
+                for (int j = 0; j < 3; ++j) {
+                    const float mine = px(x, y)[j];
+                    const float other = ((int)nx < W && (int)ny < H) ? px((int)nx, (int)ny)[j] : 0.f;
+                    diff += std::abs(mine - other);
+                }
+                if (diff > c.st.aa_threshold) return true;
+            }
+            return false;
+        };
+        std::vector<char> need((size_t)48 * 48);
+        for (size_t b = 0; b < buckets.size(); b += 2) {
+            const int bx0 = buckets[b] * 48, by0 = buckets[b + 1] * 48, bx1 = std::min(bx0 + 48, W), by1 = std::min(by0 + 48, H);
+            for (int y = by0; y < by1; ++y)
+                for (int x = bx0; x < bx1; ++x) need[(size_t)(y - by0) * 48 + (x - bx0)] = !c.st.want_adaptive_aa || too_different(x, y);
+            for (int y = by0; y < by1; ++y)
+                for (int x = bx0; x < bx1; ++x) {
+                    if (!need[(size_t)(y - by0) * 48 + (x - bx0)]) continue;
+                    float* p = px(x, y);
+                    if (c.st.show_aa) { p[0] = c.st.aa_debug_color[0]; p[1] = c.st.aa_debug_color[1]; p[2] = c.st.aa_debug_color[2]; continue; }
+                    Col result = mkc(p[0], p[1], p[2]);
+                    for (int i = 1; i < 5; ++i) {
+                        Ray ray = screen_ray(c, x + kernel[i][0], y + kernel[i][1]);
+                        ray.path = pixel_path(x, y, i);
+                        result = result + raytrace(c, ray);
+                    }
+                    result = result / (float)double(5);
+                    p[0] = result.r; p[1] = result.g; p[2] = result.b;
+                }
+        }
+    }
+    if (stats) *stats = c.stats;
+    return 0;
+}
+
+extern "C" unsigned orc_convert_to_8bit(double x) {   // ConvertTo8Bit, src/utils.h:22,34
+    const double cl = std::min(std::max(x, (double)0.f), (double)1.f);
+    return (unsigned)(int)std::floor(cl * 255.f + 0.5);
+}
