@@ -268,6 +268,15 @@ int qd_untile_async(const float* src_dev, float* dst_dev, int width, int height,
 int qd_quantize_bgr8_async(const float* rgb_dev, uint8_t* bgr_dev, int width, int height,
                            size_t row_bytes, void* hip_stream);
 
+/* Counting build of the kernels: when on, renders also fill kd_nodes_visited / tris_tested /
+ * mesh_queries (the reference's debug counters nbBBoxIntersections / nbTriIntersections /
+ * nbIntersections, src/mesh.cpp:20-22); off by default because the counters cost registers. */
+int qd_set_counting(int on);
+
+/* Replaces: nothing in the reference (its render loop cannot fail).  Returns <0 if an asynchronous
+ * launch on this scene overflowed its ray queue since the last check (synchronises the device). */
+int qd_scene_check(qd_scene* scene);
+
 void qd_scene_destroy(qd_scene* scene);
 void qd_shutdown(void);
 const char* qd_last_error(void);

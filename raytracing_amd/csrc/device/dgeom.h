@@ -1,0 +1,449 @@
+// Device intersection routines: analytic primitives, CSG, heightfield DDA and the
+// stack-based KD-tree traversal + triangle test for meshes.
+//
+// Arithmetic restates the reference function by function (cited below).  Two deliberate
+// structural differences from the CPU code, neither of which changes a result:
+//  * per-hit shading data (normal, uv, dNdx/dNdy) is NOT produced per candidate but once for
+//    the winning hit (the reference recomputes it on every passing triangle, src/mesh.cpp:141-163,
+//    only the last write survives);
+//  * the mesh KD-tree is walked iteratively with a parametric [tmin,tmax] interval and a private
+//    stack instead of the recursive, box-gated walk of src/mesh.cpp:58-92.  The triangle arithmetic,
+//    the running-distance reject (`gamma > distance`, equal passes, later triangle wins) and the leaf
+//    order are identical, so the result is the same closest hit (measured 0
+//    mismatches between the recursive walk and brute force); only exact-tie rays can differ.
+#pragma once
+#include "dmath.h"
+#include "qdtrace.h"
+
+namespace qd {
+
+struct DScene {
+    const qd_node* nodes; uint32_t n_nodes; uint32_t n_lights;
+    const qd_geom* geoms;
+    const qd_mesh* meshes;
+    const qd_heightfield* hfields;
+    const qd_shader* shaders;
+    const qd_layer* layers;
+    const qd_texture* textures;
+    const qd_proc_line* proc_lines;
+    const qd_bitmap* bitmaps;
+    const qd_light* lights;
+    const double* tri_verts;
+    const double* tri_gnormal;
+    const double* tri_shade;
+    const qd_kdnode* kd_nodes;
+    const uint32_t* leaf_tris;
+    const float* texels;
+    const float* hf_f32;
+    const double* hf_f64;
+    int env_present, env_bilinear;
+    int env_faces[6];
+};
+
+// Object-space hit record of one geometry query.
+struct GHit {
+    double dist;
+    DV ip, n;
+    double u, v;
+    double l2, l3;      // mesh barycentrics of the winning triangle
+    int tri;            // mesh-local triangle index or -1
+    int mesh;           // mesh index when tri >= 0
+    int dnd;            // 0: dNdx/dNdy left at zero (sphere, cube, polygon), 1: (1,0,0)/(0,0,1), 2: from the mesh triangle
+};
+
+struct Counters { uint32_t kd_nodes, tris, mesh_queries; };
+
+constexpr int kKdStack = 72;   // MAX_TREE_DEPTH 64 -> leaves at depth <= 65 (src/constants.h:13, src/mesh.cpp:218)
+
+// ---------------------------------------------------------------- mesh: triangle test
+// Mesh::Intersect(ray, triangle, info), src/mesh.cpp:111-168.  Returns true when the triangle
+// replaces the running hit.  The three quotients are only formed once the sign tests (which are
+// exact consequences of `gamma < 0`, `lambda2 < 0`, `lambda3 < 0`) have passed.
+template <bool STATS>
+QD_DEV bool tri_test(const DScene& S, const qd_mesh& m, uint32_t local, const DV& o, const DV& d, const DV& md,
+                     double& best, double& l2o, double& l3o, Counters& cnt) {
+    const size_t t = (size_t)m.tri_first + local;
+    const double* tv = S.tri_verts + t * 9;
+    const DV A = ld3(tv), AB = ld3(tv + 3), AC = ld3(tv + 6);
+    const DV N = cross(AB, AC);
+    const double dcr = dot(N, md);                 // Det(AB, AC, -D)
+    if (m.flags & QD_MESH_BACKCULL) {
+        // reference: ray.dir * geometryNormal > 0 with geometryNormal = N * (1/|N|).  dir.N == -dcr exactly;
+        // its sign equals the sign of dir.gnormal unless the product is within rounding of zero, where the
+        // stored unit normal decides.
+        const double mag = fabs(N.x * d.x) + fabs(N.y * d.y) + fabs(N.z * d.z);
+        bool cull;
+        if (fabs(dcr) > 1e-12 * mag) cull = dcr < 0;
+        else cull = dot(d, ld3(S.tri_gnormal + t * 3)) > 0;
+        if (cull) return false;
+    }
+    if (STATS) cnt.tris++;
+    if (fabs(dcr) < 1e-12) return false;
+    const DV H = o - A;
+    const double gn = dot(N, H);
+    const bool dneg = dcr < 0;
+    if (gn != 0 && ((gn < 0) != dneg)) return false;          // gamma < 0
+    const double l2n = dot(cross(H, AC), md);
+    if (l2n != 0 && ((l2n < 0) != dneg)) return false;        // lambda2 < 0
+    const double l3n = dot(cross(AB, H), md);
+    if (l3n != 0 && ((l3n < 0) != dneg)) return false;        // lambda3 < 0
+    const double gamma = gn / dcr;
+    if (gamma < 0 || gamma > best) return false;
+    const double l2 = l2n / dcr, l3 = l3n / dcr;
+    if (l2 < 0 || l3 < 0 || l2 + l3 > 1) return false;
+    best = gamma; l2o = l2; l3o = l3;
+    return true;
+}
+
+// Closest hit of one mesh (object space).  Replaces Mesh::Intersect(ray, info) src/mesh.cpp:30-56 and the
+// recursive KD walk :58-92.
+template <bool STATS>
+QD_DEV bool mesh_intersect(const DScene& S, int mesh_idx, const DV& o, const DV& d, GHit& out, Counters& cnt) {
+    const qd_mesh m = S.meshes[mesh_idx];
+    const DV md = -d;
+    // slab interval of the ray in the mesh box, padded like BBox::IsInside's 1e-6 (src/bbox.cpp:24-31)
+    double t0 = 0., t1 = kInf;
+    const double inv[3] = {1. / d.x, 1. / d.y, 1. / d.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double oa = comp(o, a), da = comp(d, a);
+        const double lo = m.bbox_min[a] - 1e-6, hi = m.bbox_max[a] + 1e-6;
+        if (da == 0.) { if (oa < lo || oa > hi) return false; continue; }
+        double ta = (lo - oa) * inv[a], tb = (hi - oa) * inv[a];
+        if (ta > tb) { const double s = ta; ta = tb; tb = s; }
+        t0 = fmax(t0, ta); t1 = fmin(t1, tb);
+    }
+    if (t0 > t1) return false;
+
+    double best = kInf, l2 = 0, l3 = 0;
+    int tri = -1;
+    if (m.kd_root < 0) {
+        for (uint32_t i = 0; i < m.tri_count; ++i)
+            if (tri_test<STATS>(S, m, i, o, d, md, best, l2, l3, cnt)) tri = (int)i;
+    } else {
+        if (STATS) cnt.mesh_queries++;
+        uint32_t stk_node[kKdStack];
+        double stk_t[kKdStack];
+        int sp = 0;
+        uint32_t node = (uint32_t)m.kd_root;
+        double tmin = t0, tmax = t1;
+        for (;;) {
+            qd_kdnode n = S.kd_nodes[node];
+            if (STATS) cnt.kd_nodes++;
+            uint32_t axis = n.meta & 3u;
+            while (axis != 3u) {
+                const uint32_t left = n.meta >> 2;
+                const double oa = comp(o, (int)axis);
+                const double t = (n.split - oa) * inv[axis];
+                const bool right_first = oa > n.split;                  // src/mesh.cpp:75-77
+                const uint32_t near_c = left + (right_first ? 1u : 0u), far_c = left + (right_first ? 0u : 1u);
+                const double slack = 1e-7 + 1e-9 * fabs(t);
+                if (t > tmax + slack || t < -slack) {
+                    node = near_c;                                      // plane beyond the interval or behind the origin
+                } else if (t < tmin - slack) {
+                    node = far_c;                                       // crossed before the interval starts
+                } else {                                                // (also taken when t is NaN: ray inside the plane)
+                    if (sp < kKdStack) { stk_node[sp] = far_c; stk_t[sp] = tmax; ++sp; }
+                    node = near_c;
+                    tmax = (t == t) ? fmin(tmax, t + slack) : tmax;
+                }
+                n = S.kd_nodes[node];
+                if (STATS) cnt.kd_nodes++;
+                axis = n.meta & 3u;
+            }
+            const uint32_t first = n.meta >> 2;
+            for (uint32_t i = 0; i < n.count; ++i) {
+                const uint32_t local = S.leaf_tris[first + i];
+                if (tri_test<STATS>(S, m, local, o, d, md, best, l2, l3, cnt)) tri = (int)local;
+            }
+            // front-to-back: a hit inside this leaf's interval cannot be beaten by later leaves
+            if (tri >= 0 && best <= tmax - (2e-7 + 2e-9 * fabs(tmax))) break;
+            if (sp == 0) break;
+            --sp;
+            node = stk_node[sp];
+            tmin = tmax;
+            tmax = stk_t[sp];
+        }
+    }
+    if (tri < 0) return false;
+    out.dist = best;
+    out.ip = o + d * best;
+    out.tri = tri; out.mesh = mesh_idx; out.l2 = l2; out.l3 = l3; out.dnd = 2;
+    return true;
+}
+
+// Shading data of a mesh hit (src/mesh.cpp:141-163), evaluated once for the winner.
+QD_DEV void mesh_finish(const DScene& S, GHit& h, DV& dndx, DV& dndy, bool want_dnd) {
+    const qd_mesh& m = S.meshes[h.mesh];
+    const size_t t = (size_t)m.tri_first + (uint32_t)h.tri;
+    const double* sh = S.tri_shade + t * 21;
+    if (!(m.flags & QD_MESH_FACETED)) {
+        const DV nA = ld3(sh), nB = ld3(sh + 3), nC = ld3(sh + 6);
+        h.n = normalize(nA + h.l2 * (nB - nA) + h.l3 * (nC - nA));
+    } else {
+        h.n = ld3(S.tri_gnormal + t * 3);
+    }
+    h.u = sh[9] + h.l2 * (sh[11] - sh[9]) + h.l3 * (sh[13] - sh[9]);
+    h.v = sh[10] + h.l2 * (sh[12] - sh[10]) + h.l3 * (sh[14] - sh[10]);
+    if (want_dnd) { dndx = ld3(sh + 15); dndy = ld3(sh + 18); }
+}
+
+// ---------------------------------------------------------------- boxes (src/bbox.cpp)
+QD_DEV bool box_inside(const double* mn, const double* mx, const DV& p) {
+    return is_between(p.x, mn[0], mx[0], 1e-6) && is_between(p.y, mn[1], mx[1], 1e-6) && is_between(p.z, mn[2], mx[2], 1e-6);
+}
+QD_DEV double box_closest(const double* mn, const double* mx, const DV& start, const DV& dir) {   // :99-137
+    if (box_inside(mn, mx, start)) return 0.;
+    double best = kInf;
+    for (int dim = 0; dim < 3; ++dim) {
+        const double d = comp(dir, dim), s = comp(start, dim), lo = mn[dim], hi = mx[dim];
+        if (d < 0 && s < lo) continue;
+        if (d > 0 && s > hi) continue;
+        if (is_zero(d, 1e-9)) continue;
+        const double mul = 1. / d;
+        const int u = (dim == 0) ? 1 : 0, v = (dim == 2) ? 1 : 2;
+        for (int j = 0; j < 2; ++j) {
+            const double dist = ((j ? hi : lo) - s) * mul;
+            if (dist < 0) continue;
+            const double x = comp(start, u) + comp(dir, u) * dist;
+            if (is_between(x, mn[u], mx[u], 0)) {
+                const double y = comp(start, v) + comp(dir, v) * dist;
+                if (is_between(y, mn[v], mx[v], 0)) best = fmin(best, dist);
+            }
+        }
+    }
+    return best;
+}
+
+// IntersectTriangleFast, src/mesh.cpp:542-580
+QD_DEV bool tri_fast(const DV& start, const DV& dir, const DV& A, const DV& B, const DV& C, double& dist) {
+    const DV AB = B - A, AC = C - A, D = -dir, H = start - A;
+    const DV n = cross(AB, AC);
+    const double dcr = dot(n, D);
+    if (fabs(dcr) < 1e-12) return false;
+    const double gamma = dot(n, H) / dcr;
+    if (gamma < 0 || gamma > dist) return false;
+    const double l2 = dot(cross(H, AC), D) / dcr;
+    const double l3 = dot(cross(AB, H), D) / dcr;
+    if (l2 < 0 || l3 < 0 || l2 + l3 > 1) return false;
+    dist = gamma;
+    return true;
+}
+
+// ---------------------------------------------------------------- heightfield (src/heightfield.cpp:20-100, :216-245)
+QD_DEV bool hf_intersect(const DScene& S, int hf, const DV& start, const DV& dir, GHit& out) {
+    const qd_heightfield& h = S.hfields[hf];
+    const float* heights = S.hf_f32 + h.heights_off;
+    const float* maxh = S.hf_f32 + h.maxheights_off;
+    const float* highmap = S.hf_f32 + h.highmap_off;
+    const double* normals = S.hf_f64 + h.normals_off;
+    const int W = (int)h.width, H = (int)h.height;
+    auto get_height = [&](int x, int y) { x = min(max(x, 0), W - 1); y = min(max(y, 0), H - 1); return heights[(size_t)y * W + x]; };
+    const DV step = dir / (dsqrt(sqr(dir.x) + sqr(dir.z)));
+    const double dist = box_closest(h.bbox_min, h.bbox_max, start, dir);
+    const double mx = 1.0 / dir.x, mz = 1.0 / dir.z;
+    DV p = start + dir * (dist + 1e-6);
+    while (box_inside(h.bbox_min, h.bbox_max, p)) {
+        int x0 = (int)floor(p.x), z0 = (int)floor(p.z);
+        if (!(x0 < 0 || x0 >= W || z0 < 0 || z0 >= H) && h.use_optimization) {
+            int k = 0;
+            while (k < h.max_k && fmin(p.y, p.y + dir.y * (1 << k)) > (double)highmap[((size_t)z0 * W + x0) * 16 + k]) ++k;
+            --k;
+            if (k >= 0) {
+                p = p + dir * (1 << k);
+                x0 = (int)floor(p.x); z0 = (int)floor(p.z);
+            }
+        }
+        if (x0 < 0 || x0 >= W || z0 < 0 || z0 >= H) break;
+        const double lx = dir.x > 0 ? (ceil(p.x) - p.x) * mx : (floor(p.x) - p.x) * mx;
+        const double lz = dir.z > 0 ? (ceil(p.z) - p.z) * mz : (floor(p.z) - p.z) * mz;
+        const DV p_next = p + step * (fmin(lx, lz) + 1e-6);
+        if (fmin(p.y, p_next.y) < (double)maxh[(size_t)z0 * W + x0]) {
+            double closest = kInf;
+            const DV A = mk(x0, get_height(x0, z0), z0);
+            const DV B = mk(x0 + 1, get_height(x0 + 1, z0), z0);
+            const DV C = mk(x0 + 1, get_height(x0 + 1, z0 + 1), z0 + 1);
+            const DV D = mk(x0, get_height(x0, z0 + 1), z0 + 1);
+            if (tri_fast(start, dir, A, B, D, closest) || tri_fast(start, dir, B, C, D, closest)) {
+                out.dist = closest;
+                out.ip = start + dir * closest;
+                // GetNormal: bilinear in float weights
+                const float fx = static_cast<float>(out.ip.x), fy = static_cast<float>(out.ip.z);
+                unsigned ux = (unsigned)floorf(fx), uy = (unsigned)floorf(fy);
+                const float pw = fx - ux, qw = fy - uy;
+                ux = min(ux, h.width - 1); uy = min(uy, h.height - 1);
+                const unsigned x1 = min(h.width - 1, ux + 1), y1 = min(h.height - 1, uy + 1);
+                auto nrm = [&](unsigned x, unsigned y) { return ld3(normals + ((size_t)y * W + x) * 3); };
+                out.n = nrm(ux, uy) * ((1 - pw) * (1 - qw)) + nrm(x1, uy) * ((pw) * (1 - qw)) +
+                        nrm(ux, y1) * ((1 - pw) * (qw)) + nrm(x1, y1) * ((pw) * (qw));
+                out.u = out.ip.x / h.width;
+                out.v = out.ip.z / h.height;
+                out.tri = -1; out.dnd = 1;
+                return true;
+            }
+        }
+        p = p_next;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------- analytic primitives (src/geometry.cpp)
+QD_DEV bool plane_intersect(const qd_geom& g, const DV& start, const DV& dir, GHit& out) {   // :6-28
+    const double height = g.p[0], limit = g.p[1];
+    if (start.y > height && dir.y >= 0.) return false;
+    if (start.y < height && dir.y <= 0.) return false;
+    const double sf = (height - start.y) / dir.y;
+    const DV ip = start + dir * sf;
+    if (fabs(ip.x) > limit || fabs(ip.z) > limit) return false;
+    out.ip = ip; out.dist = sf;
+    out.n = mk(0., start.y > height ? 1. : -1., 0.);
+    out.u = ip.x; out.v = ip.z;
+    out.tri = -1; out.dnd = 1;
+    return true;
+}
+
+QD_DEV bool sphere_intersect(const qd_geom& g, const DV& start, const DV& dir, GHit& out) {  // :49-87
+    const DV center = mk(g.p[0], g.p[1], g.p[2]);
+    const double R = g.p[3];
+    const DV H = start - center;
+    const double A = 1;
+    const double B = 2 * dot(H, dir);
+    const double C = len_sqr(H) - sqr(R);
+    const double discr = sqr(B) - 4 * A * C;
+    if (discr < 0) return false;
+    const double sq = dsqrt(discr);
+    const double p1 = (-B - sq) / (2 * A);
+    const double p2 = (-B + sq) / (2 * A);
+    double p;
+    if (p1 > 0) p = p1; else if (p2 > 0) p = p2; else return false;
+    out.dist = p;
+    out.ip = start + dir * p;
+    const DV rel = out.ip - center;
+    out.n = normalize(rel);
+    out.u = (atan2(rel.z, rel.x) + kPi) / (2 * kPi);
+    out.v = -(asin(rel.y / R) + kPi / 2) / kPi;
+    out.tri = -1; out.dnd = 0;
+    return true;
+}
+
+QD_DEV void cube_side(const qd_geom& g, double level, double s, double d, const DV& start, const DV& dir,
+                      double nx, double ny, double nz, GHit& out) {                          // :107-148
+    const double cx = g.p[0], cy = g.p[1], cz = g.p[2], hs = g.p[3];
+    if (s > level && d >= 0) return;
+    if (s < level && d <= 0) return;
+    const double sf = (level - s) / d;
+    const DV ip = start + dir * sf;
+    if (ip.y > cy + hs + 1e-6) return;
+    if (ip.y < cy - hs - 1e-6) return;
+    if (ip.x > cx + hs + 1e-6) return;
+    if (ip.x < cx - hs - 1e-6) return;
+    if (ip.z > cz + hs + 1e-6) return;
+    if (ip.z < cz - hs - 1e-6) return;
+    if (out.dist <= sf) return;
+    out.ip = ip; out.dist = sf; out.n = mk(nx, ny, nz);
+    if (ny == 0) { out.u = ip.x + ip.z; out.v = ip.y; }
+    else { out.u = ip.x; out.v = ip.z; }
+}
+
+QD_DEV bool cube_intersect(const qd_geom& g, const DV& start, const DV& dir, GHit& out) {    // :150-162
+    const double cx = g.p[0], cy = g.p[1], cz = g.p[2], hs = g.p[3];
+    out.dist = kInf; out.tri = -1; out.dnd = 0;
+    cube_side(g, cx - hs, start.x, dir.x, start, dir, -1, 0, 0, out);
+    cube_side(g, cx + hs, start.x, dir.x, start, dir, +1, 0, 0, out);
+    cube_side(g, cy - hs, start.y, dir.y, start, dir, 0, -1, 0, out);
+    cube_side(g, cy + hs, start.y, dir.y, start, dir, 0, +1, 0, out);
+    cube_side(g, cz - hs, start.z, dir.z, start, dir, 0, 0, -1, out);
+    cube_side(g, cz + hs, start.z, dir.z, start, dir, 0, 0, +1, out);
+    return out.dist < kInf;
+}
+
+QD_DEV bool regpoly_intersect(const qd_geom& g, const DV& start, const DV& dir, GHit& out) { // :259-296
+    const DV cn = mk(g.p[0], g.p[1], g.p[2]);
+    const double R = g.p[3];
+    const unsigned sides = (unsigned)g.a;
+    if (start.y > cn.y && dir.y >= 0.) return false;
+    if (start.y < cn.y && dir.y <= 0.) return false;
+    const double sf = (cn.y - start.y) / dir.y;
+    const DV ip = start + dir * sf;
+    const DV dd = ip - cn;
+    double angle = atan2(dd.z, dd.x);
+    if (angle < 0) angle += 2 * kPi;
+    const double side_angle = 2 * kPi / sides;
+    const unsigned k1 = (unsigned)(angle / side_angle);
+    const unsigned k2 = (k1 + 1 == sides ? 0 : k1 + 1);
+    const DV vk1 = mk(cn.x + cos(k1 * side_angle) * R, cn.y, cn.z + sin(k1 * side_angle) * R);
+    const DV vk2 = mk(cn.x + cos(k2 * side_angle) * R, cn.y, cn.z + sin(k2 * side_angle) * R);
+    auto cross_scalar = [](const DV& l, const DV& r) { return l.x * r.y + l.y * r.z + l.z * r.x - l.x * r.z - l.y * r.x - l.z * r.y; };
+    const int s1 = sign_of(cross_scalar(vk1 - cn, ip - vk1));
+    const int s2 = sign_of(cross_scalar(vk2 - vk1, ip - vk2));
+    const int s3 = sign_of(cross_scalar(cn - vk2, ip - cn));
+    if (!((s1 >= 0 && s2 >= 0 && s3 >= 0) || (s1 <= 0 && s2 <= 0 && s3 <= 0))) return false;
+    out.ip = ip; out.dist = sf;
+    out.n = mk(0., start.y > cn.y ? 1. : -1., 0.);
+    out.u = ip.x - cn.x; out.v = ip.z - cn.z;
+    out.tri = -1; out.dnd = 0;
+    return true;
+}
+
+// IsInside of a non-CSG geometry
+QD_DEV bool leaf_inside(const qd_geom& g, const DV& p) {
+    switch (g.type) {
+        case QD_GEOM_PLANE: return p.y == g.p[0];
+        case QD_GEOM_SPHERE: return len_sqr(p - mk(g.p[0], g.p[1], g.p[2])) <= sqr(g.p[3]);
+        case QD_GEOM_CUBE: return is_zero(p.x - g.p[0], g.p[3]) & is_zero(p.y - g.p[1], g.p[3]) & is_zero(p.z - g.p[2], g.p[3]);
+        case QD_GEOM_REGPOLY: return p.y == g.p[1];
+        default: return false;
+    }
+}
+
+template <bool STATS>
+QD_DEV bool leaf_intersect(const DScene& S, const qd_geom& g, const DV& start, const DV& dir, GHit& out, Counters& cnt) {
+    switch (g.type) {
+        case QD_GEOM_PLANE: return plane_intersect(g, start, dir, out);
+        case QD_GEOM_SPHERE: return sphere_intersect(g, start, dir, out);
+        case QD_GEOM_CUBE: return cube_intersect(g, start, dir, out);
+        case QD_GEOM_REGPOLY: return regpoly_intersect(g, start, dir, out);
+        case QD_GEOM_MESH: return mesh_intersect<STATS>(S, g.a, start, dir, out, cnt);
+        case QD_GEOM_HEIGHTFIELD: return hf_intersect(S, g.a, start, dir, out);
+        default: return false;
+    }
+}
+
+QD_DEV bool csg_op(int op, bool a, bool b) { return op == QD_CSG_AND ? (a && b) : (op == QD_CSG_PLUS ? (a || b) : (a && !b)); }
+
+// CsgOp::Intersect, src/geometry.cpp:184-234.  Operands must be non-CSG geometries on the device
+// (qd_scene_create rejects nested CSG).
+template <bool STATS>
+QD_DEV bool csg_intersect(const DScene& S, const qd_geom& g, const DV& start, const DV& dir, GHit& out, Counters& cnt) {
+    const qd_geom ga = S.geoms[g.a], gb = S.geoms[g.b];
+    GHit li, ri;
+    bool inA = leaf_inside(ga, start), inB = leaf_inside(gb, start);
+    const bool cur = csg_op(g.c, inA, inB);
+    bool lhit = leaf_intersect<STATS>(S, ga, start, dir, li, cnt);
+    bool rhit = leaf_intersect<STATS>(S, gb, start, dir, ri, cnt);
+    while (lhit || rhit) {
+        if (lhit && (!rhit || li.dist <= ri.dist)) {
+            inA = !inA;
+            if (csg_op(g.c, inA, inB) != cur) { out = li; return true; }
+            const double prev = li.dist;
+            lhit = leaf_intersect<STATS>(S, ga, li.ip + dir * 1e-6, dir, li, cnt);
+            if (lhit) li.dist += prev + 1e-6;
+        } else if (rhit && (!lhit || ri.dist <= li.dist)) {
+            inB = !inB;
+            if (csg_op(g.c, inA, inB) != cur) { out = ri; return true; }
+            const double prev = ri.dist;
+            rhit = leaf_intersect<STATS>(S, gb, ri.ip + dir * 1e-6, dir, ri, cnt);
+            if (rhit) ri.dist += prev + 1e-6;
+        }
+    }
+    return false;
+}
+
+template <bool STATS>
+QD_DEV bool geom_intersect(const DScene& S, int gi, const DV& start, const DV& dir, GHit& out, Counters& cnt) {
+    const qd_geom g = S.geoms[gi];
+    if (g.type == QD_GEOM_CSG) return csg_intersect<STATS>(S, g, start, dir, out, cnt);
+    return leaf_intersect<STATS>(S, g, start, dir, out, cnt);
+}
+
+}  // namespace qd

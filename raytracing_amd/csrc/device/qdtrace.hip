@@ -1,0 +1,733 @@
+// libqdtrace.so -- HIP (gfx950 / MI355X) trace path behind the C-ABI of include/qdtrace.h.
+//
+// One persistent kernel replaces the reference's recursive Raytrace() (src/main.cpp:18-56):
+// every lane owns one pixel at a time and runs an explicit, bounded LIFO queue of ray tasks
+// (radiance rays and shadow rays) that lives in an HBM workspace laid out lane-interleaved
+// (word-major, lanes contiguous) so that a wave's queue traffic coalesces.  Colour is
+// accumulated as sum(weight * leaf colour): the reference's shading tree is linear in its leaves
+// (SURVEY.md section 3C), so recursion unrolls into weights.  Waves pull 8x8-pixel units from
+// eight work queues (one per XCD label, with stealing) so that each XCD's private L2 sees one
+// contiguous image region and therefore one region of the KD-tree.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "dshade.h"
+#include "qdtrace.h"
+
+using namespace qd;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Ray task queue entry: 10 x 8-byte words per slot.
+//   0..2 origin, 3..5 direction, 6 = (w.r, w.g), 7 = (w.b, flags|depth),
+//   radiance ray : 8 = path id (low 32 bits)
+//   shadow ray   : 8 = squared distance to the light, 9 = intensity / |ip - light|^2
+constexpr int kEntryWords = 10;
+constexpr uint32_t kFlagShadow = 0x80000000u, kFlagPrimary = 0x40000000u, kDepthMask = 0x00ffffffu;
+
+struct Params {
+    qd_camera cam;
+    int W, H;
+    float ambient[3];
+    uint32_t max_depth;
+    int mode;                     // 0 = rectangle, 1 = interleaved tiles (compacted output)
+    int x0, y0, rw, rh;           // rectangle
+    int tile, tiles_x, phase, stride;
+    uint32_t n_units;             // 8x8 pixel units to render
+    uint32_t units_x;             // rectangle mode: units per row
+    uint32_t* queue_ctr;          // 8 work-queue counters (zeroed before launch)
+    uint64_t* stack;              // ray task workspace
+    uint32_t stack_cap;           // slots per lane
+    uint32_t n_lanes;
+    float* rgb; size_t pitch;     // output (pitch in floats, rectangle mode)
+    int32_t* hit_node; int32_t* hit_tri; double* hit_dist;
+    unsigned long long* stats;    // 8 counters, see qd_stats
+    int* error_flag;
+};
+
+struct Task {
+    DV o, d;
+    Col w;
+    uint32_t flags_depth;
+    uint32_t path;
+    double aux0, aux1;
+};
+
+QD_DEV uint64_t pack2f(float a, float b) { return (uint64_t)__float_as_uint(a) | ((uint64_t)__float_as_uint(b) << 32); }
+QD_DEV uint64_t pack_fu(float a, uint32_t b) { return (uint64_t)__float_as_uint(a) | ((uint64_t)b << 32); }
+
+struct LaneQueue {
+    uint64_t* base; size_t stride; uint32_t cap; int sp; int* err;
+    QD_DEV void push(const Task& t) {
+        if ((uint32_t)sp >= cap) { *err = 1; return; }
+        uint64_t* p = base + (size_t)sp * kEntryWords * stride;
+        p[0 * stride] = __double_as_longlong(t.o.x); p[1 * stride] = __double_as_longlong(t.o.y); p[2 * stride] = __double_as_longlong(t.o.z);
+        p[3 * stride] = __double_as_longlong(t.d.x); p[4 * stride] = __double_as_longlong(t.d.y); p[5 * stride] = __double_as_longlong(t.d.z);
+        p[6 * stride] = pack2f(t.w.r, t.w.g);
+        p[7 * stride] = pack_fu(t.w.b, t.flags_depth);
+        if (t.flags_depth & kFlagShadow) { p[8 * stride] = __double_as_longlong(t.aux0); p[9 * stride] = __double_as_longlong(t.aux1); }
+        else p[8 * stride] = t.path;
+        ++sp;
+    }
+    QD_DEV Task pop() {
+        --sp;
+        const uint64_t* p = base + (size_t)sp * kEntryWords * stride;
+        Task t;
+        t.o = mk(__longlong_as_double(p[0 * stride]), __longlong_as_double(p[1 * stride]), __longlong_as_double(p[2 * stride]));
+        t.d = mk(__longlong_as_double(p[3 * stride]), __longlong_as_double(p[4 * stride]), __longlong_as_double(p[5 * stride]));
+        const uint64_t a = p[6 * stride], b = p[7 * stride];
+        t.w = mkc(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)), __uint_as_float((uint32_t)b));
+        t.flags_depth = (uint32_t)(b >> 32);
+        if (t.flags_depth & kFlagShadow) { t.aux0 = __longlong_as_double(p[8 * stride]); t.aux1 = __longlong_as_double(p[9 * stride]); t.path = 0; }
+        else { t.path = (uint32_t)p[8 * stride]; t.aux0 = t.aux1 = 0; }
+        return t;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Shadow query: product of shadowTransparency over all nodes whose closest hit is nearer than the
+// light (ShadingHelper::GetShadowTransparency, src/shadinghelper.cpp:20-40).  Once the product is
+// exactly 0 no later factor can change it, so the node loop stops there.
+template <bool STATS>
+QD_DEV float shadow_trace(const DScene& S, const DV& o, const DV& d, double target, Counters& cnt) {
+    float result = 1.f;
+    for (uint32_t i = 0; i < S.n_nodes; ++i) {
+        const qd_node& n = S.nodes[i];
+        const ObjRay r = to_object(n, o, d);
+        GHit h;
+        if (!geom_intersect<STATS>(S, n.geom, r.o, r.d, h, cnt)) continue;
+        const double dw = h.dist / r.len;
+        if (sqr(dw) < target) {
+            result *= n.shadow_transparency;
+            if (result == 0.f) break;
+        }
+    }
+    return result;
+}
+
+// Closest hit over all nodes in file order, strict '<' (src/main.cpp:23-38).
+template <bool STATS>
+QD_DEV int closest_hit(const DScene& S, const DV& o, const DV& d, GHit& best, double& best_dw, Counters& cnt) {
+    int node = -1;
+    best_dw = kInf;
+    for (uint32_t i = 0; i < S.n_nodes; ++i) {
+        const qd_node& n = S.nodes[i];
+        const ObjRay r = to_object(n, o, d);
+        GHit h;
+        if (!geom_intersect<STATS>(S, n.geom, r.o, r.d, h, cnt)) continue;
+        const double dw = h.dist / r.len;
+        if (best_dw <= dw) continue;
+        best_dw = dw; node = (int)i; best = h;
+    }
+    return node;
+}
+
+// World-space IntersectionInfo of the winning hit (src/geometry.cpp:331-338).
+QD_DEV void assemble_info(const DScene& S, const qd_node& n, GHit& h, double dw, const DV& ray_dir, Info& info) {
+    const bool want_dnd = n.bump_tex >= 0;
+    DV dndx = mk(0, 0, 0), dndy = mk(0, 0, 0);
+    if (h.tri >= 0) mesh_finish(S, h, dndx, dndy, want_dnd);
+    else if (h.dnd == 1) { dndx = mk(1, 0, 0); dndy = mk(0, 0, 1); }
+    info.normal = normalize(mul_mat(h.n, n.MinvT));
+    if (want_dnd) {
+        info.dNdx = normalize(mul_mat(dndx, n.M));
+        info.dNdy = normalize(mul_mat(dndy, n.M));
+    } else { info.dNdx = dndx; info.dNdy = dndy; }
+    info.ip = mul_mat(h.ip, n.M) + ld3(n.offset);
+    info.distance = dw;
+    info.u = h.u; info.v = h.v;
+    info.rayDir = ray_dir;
+}
+
+// One non-layered shader at a hit: adds its direct colour to acc and queues its rays
+// (Lambert/Phong/BlinnPhong/OrenNayar/Const/Reflection/Refraction::Shade, src/shading.cpp).
+QD_DEV void eval_leaf_shader(const DScene& S, const Params& P, int si, Col w, uint32_t slot, const Task& ray, uint32_t depth,
+                             const Info& info, Col& acc, LaneQueue& q) {
+    const qd_shader sh = S.shaders[si];
+    switch (sh.type) {
+        case QD_SH_CONST: acc = acc + w * ldc(sh.color); break;
+        case QD_SH_LAMBERT: case QD_SH_PHONG: case QD_SH_BLINNPHONG: case QD_SH_ORENNAYAR: {
+            const Col diffuse = sh.tex >= 0 ? tex_sample(S, sh.tex, info) : ldc(sh.color);
+            acc = acc + w * (diffuse * ldc(P.ambient));
+            for (uint32_t li = 0; li < S.n_lights; ++li) {
+                const qd_light L = S.lights[li];
+                const DV lpos = ld3(L.pos);
+                Col cl;
+                if (sh.type == QD_SH_ORENNAYAR) {                                  // :102-126
+                    const double sigma2 = sqr(sh.p0);
+                    const double VdotN = dot(-ray.d, info.normal);
+                    const DV lightDir = normalize(lpos - info.ip);
+                    const double LdotV = dot(lightDir, -ray.d);
+                    const double LdotN = dot(lightDir, info.normal);
+                    const double sv = LdotV - LdotN * VdotN;
+                    const double t = (sv <= 0. ? 1. : fmax(LdotN, VdotN));
+                    const double a = 1 - 0.5 * sigma2 / (sigma2 + 0.33);
+                    const double b = 0.45 * sigma2 / (sigma2 + 0.09);
+                    cl = diffuse * (float)(LdotN * (a + b * sv / t));
+                } else {
+                    const DV lightDir = normalize(info.ip - lpos);                 // :17-19, :59-61
+                    const DV normal = faceforward(lightDir, info.normal);
+                    const double lambert = dot(normal, -lightDir);
+                    cl = diffuse * (float)lambert;
+                    if (sh.type == QD_SH_PHONG) {                                  // :42-50
+                        const DV refl = reflect(lightDir, normal);
+                        const double cg = dot(-ray.d, refl);
+                        const double spec = cg > 0. ? pow(cg, sh.p1) : 0.;
+                        cl = cl + mkc(1.f, 1.f, 1.f) * (float)spec * (float)sh.p0;
+                    } else if (sh.type == QD_SH_BLINNPHONG) {                      // :93-100
+                        const DV ld = normalize(lpos - info.ip);
+                        const DV half = normalize(ld - ray.d);
+                        const double spec = pow(fmax(dot(info.normal, half), 0.), sh.p1);
+                        cl = cl + mkc(1.f, 1.f, 1.f) * (float)spec * (float)sh.p0;
+                    }
+                }
+                // shadow ray towards the light (ShadingHelper::GetLightContribution, src/shadinghelper.cpp:11-18)
+                Task s;
+                s.o = info.ip + info.normal * 1e-6;
+                s.d = normalize(lpos - s.o);
+                s.aux0 = len_sqr(lpos - s.o);
+                s.aux1 = L.intensity / len_sqr(info.ip - lpos);
+                s.w = w * cl;
+                s.flags_depth = kFlagShadow | depth;
+                s.path = 0;
+                q.push(s);
+            }
+            break;
+        }
+        case QD_SH_REFL: {                                                         // :155-198
+            const DV n = faceforward(ray.d, info.normal);
+            Task r;
+            r.o = info.ip + n * 0.000001;
+            r.flags_depth = depth + 1;
+            r.aux0 = r.aux1 = 0;
+            if (sh.p1 == 1) {
+                r.d = reflect(ray.d, n);
+                r.w = w * (float)sh.p0;
+                r.path = path_child(ray.path, slot, 0);
+                q.push(r);
+            } else {
+                const int count = depth > 0 ? 2 : sh.i0;
+                const Col wi = (w * (float)sh.p0) / (float)count;
+                DV a, b;
+                orthonormal_system(n, a, b);
+                const double k = tan((1 - sh.p1) * kPi / 2);
+                for (int i = 0; i < count; ++i) {
+                    const double angle = random01(ray.path, slot * 64u + (uint32_t)i, 0) * 2 * kPi;   // src/utils.cpp:63-69
+                    const double radius = dsqrt(random01(ray.path, slot * 64u + (uint32_t)i, 1));
+                    double x = cos(angle) * radius, y = sin(angle) * radius;
+                    x *= k; y *= k;
+                    const DV mn = n + a * x + b * y;
+                    r.d = reflect(ray.d, mn);
+                    r.w = wi;
+                    r.path = path_child(ray.path, slot, (uint32_t)i + 1);
+                    q.push(r);
+                }
+            }
+            break;
+        }
+        case QD_SH_REFR: {                                                         // :213-238
+            DV refr;
+            if (dot(ray.d, info.normal) < 0.) refr = refract(ray.d, info.normal, 1 / sh.p0);
+            else refr = refract(ray.d, -info.normal, sh.p0);
+            if (len_sqr(refr) == 0) { acc = acc + w * mkc(1, 0, 0); break; }       // total internal reflection: red
+            Task r;
+            r.o = info.ip - faceforward(ray.d, info.normal) * 0.000001;
+            r.d = refr;
+            r.w = w * (float)sh.p1;
+            r.flags_depth = depth + 1;
+            r.path = path_child(ray.path, slot, 0);
+            r.aux0 = r.aux1 = 0;
+            q.push(r);
+            break;
+        }
+        default: break;   // nested Layered is rejected by qd_scene_create
+    }
+}
+
+QD_DEV uint32_t fetch_unit(const Params& P, uint32_t home) {
+    const uint32_t per = (P.n_units + 7u) / 8u;
+    for (uint32_t i = 0; i < 8; ++i) {
+        const uint32_t qi = (home + i) & 7u;
+        const uint32_t lo = qi * per;
+        if (lo >= P.n_units) continue;
+        const uint32_t size = min(per, P.n_units - lo);
+        if (__hip_atomic_load(&P.queue_ctr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= size) continue;
+        const uint32_t v = atomicAdd(&P.queue_ctr[qi], 1u);
+        if (v < size) return lo + v;
+    }
+    return 0xffffffffu;
+}
+
+QD_DEV uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(64) void trace_kernel(const DScene S, const Params P) {
+    const uint32_t lane = threadIdx.x;
+    const size_t gl = (size_t)blockIdx.x * 64 + lane;
+    LaneQueue q;
+    q.base = P.stack + gl; q.stride = P.n_lanes; q.cap = P.stack_cap; q.sp = 0; q.err = P.error_flag;
+    Counters cnt; cnt.kd_nodes = cnt.tris = cnt.mesh_queries = 0;
+    uint32_t n_rays = 0, n_primary = 0, n_shadow = 0, n_killed = 0;
+    const DV TL = ld3(P.cam.top_left), TR = ld3(P.cam.top_right), BL = ld3(P.cam.bottom_left), pos = ld3(P.cam.position);
+
+    for (;;) {
+        uint32_t unit = 0;
+        if (lane == 0) unit = fetch_unit(P, blockIdx.x & 7u);
+        unit = __shfl(unit, 0, 64);
+        if (unit == 0xffffffffu) break;
+
+        // unit -> pixel
+        int x, y; size_t out_idx; bool valid;
+        const int lx8 = lane & 7, ly8 = lane >> 3;
+        if (P.mode == 0) {
+            const int ux = unit % P.units_x, uy = unit / P.units_x;
+            const int px = ux * 8 + lx8, py = uy * 8 + ly8;
+            x = P.x0 + px; y = P.y0 + py;
+            valid = px < P.rw && py < P.rh;
+            out_idx = (size_t)py * P.rw + px;
+        } else {
+            const int sub_per_side = P.tile / 8, spt = sub_per_side * sub_per_side;
+            const int k = unit / spt, sb = unit % spt;
+            const int t = P.phase + k * P.stride;
+            const int tx = t % P.tiles_x, ty = t / P.tiles_x;
+            const int lx = (sb % sub_per_side) * 8 + lx8, ly = (sb / sub_per_side) * 8 + ly8;
+            x = tx * P.tile + lx; y = ty * P.tile + ly;
+            valid = x < P.W && y < P.H;
+            out_idx = (size_t)k * P.tile * P.tile + (size_t)ly * P.tile + lx;
+        }
+
+        Col acc = mkc(0, 0, 0);
+        if (valid) {
+            // Camera::GetScreenRay, src/camera.cpp:26-41 (integer pixel coordinates, no +0.5)
+            const DV through = TL + (TR - TL) * ((double)x / P.W) + (BL - TL) * ((double)y / P.H);
+            Task t;
+            t.o = pos; t.d = normalize(through - pos);
+            t.w = mkc(1.f, 1.f, 1.f);
+            t.flags_depth = kFlagPrimary;
+            t.path = pixel_path(x, y, 0);
+            t.aux0 = t.aux1 = 0;
+            q.push(t);
+            ++n_primary;
+        }
+
+        while (q.sp > 0) {
+            const Task t = q.pop();
+            if (t.flags_depth & kFlagShadow) {
+                ++n_shadow;
+                const float st = shadow_trace<STATS>(S, t.o, t.d, t.aux0, cnt);
+                acc = acc + t.w * (float)((double)st * t.aux1);
+                continue;
+            }
+            const uint32_t depth = t.flags_depth & kDepthMask;
+            if (depth > P.max_depth) { ++n_killed; continue; }          // src/main.cpp:20-21
+            ++n_rays;
+            GHit h; double dw;
+            const int node = closest_hit<STATS>(S, t.o, t.d, h, dw, cnt);
+            if ((t.flags_depth & kFlagPrimary) && P.hit_node) {
+                P.hit_node[out_idx] = node;
+                P.hit_tri[out_idx] = node >= 0 ? h.tri : -1;
+                P.hit_dist[out_idx] = node >= 0 ? dw : 0.;
+            }
+            if (node < 0) {
+                if (S.env_present) acc = acc + t.w * env_lookup(S, t.d);
+                continue;
+            }
+            const qd_node& n = S.nodes[node];
+            Info info;
+            assemble_info(S, n, h, dw, t.d, info);
+            if (n.bump_tex >= 0) tex_modify_normal(S, n.bump_tex, info);
+            const qd_shader top = S.shaders[n.shader];
+            if (top.type == QD_SH_LAYERED) {
+                // Layered::Shade (src/shading.cpp:260-275): result = b*layer + (1-b)*result, i.e. layer i carries
+                // b_i * prod_{j>i}(1-b_j); walk the layers from the last to the first keeping that suffix product.
+                Col suffix = mkc(1.f, 1.f, 1.f);
+                for (int i = top.i1 - 1; i >= 0; --i) {
+                    const qd_layer l = S.layers[top.i0 + i];
+                    Col blend = ldc(l.blend);
+                    if (l.tex >= 0) blend = blend * tex_sample(S, l.tex, info);
+                    eval_leaf_shader(S, P, l.shader, t.w * (blend * suffix), (uint32_t)i + 1, t, depth, info, acc, q);
+                    suffix = suffix * (mkc(1.f, 1.f, 1.f) - blend);
+                }
+            } else {
+                eval_leaf_shader(S, P, n.shader, t.w, 0, t, depth, info, acc, q);
+            }
+        }
+        if (valid) {
+            float* o = (P.mode == 0) ? P.rgb + (size_t)(y - P.y0) * P.pitch + (size_t)(x - P.x0) * 3 : P.rgb + out_idx * 3;
+            o[0] = acc.r; o[1] = acc.g; o[2] = acc.b;
+        }
+    }
+
+    if (P.stats) {
+        const uint32_t r = wave_sum(n_rays), p = wave_sum(n_primary), s = wave_sum(n_shadow), k = wave_sum(n_killed);
+        uint32_t a = 0, b = 0, c = 0;
+        if (STATS) { a = wave_sum(cnt.kd_nodes); b = wave_sum(cnt.tris); c = wave_sum(cnt.mesh_queries); }
+        if (lane == 0) {
+            atomicAdd(&P.stats[0], (unsigned long long)r + s);
+            atomicAdd(&P.stats[1], (unsigned long long)p);
+            atomicAdd(&P.stats[2], (unsigned long long)s);
+            atomicAdd(&P.stats[3], (unsigned long long)k);
+            if (STATS) {
+                atomicAdd(&P.stats[4], (unsigned long long)a);
+                atomicAdd(&P.stats[5], (unsigned long long)b);
+                atomicAdd(&P.stats[6], (unsigned long long)c);
+            }
+        }
+    }
+}
+
+__global__ void untile_kernel(const float* __restrict__ src, float* __restrict__ dst, int W, int H, int tile, int stride, int tpr) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    const int tiles_x = (W + tile - 1) / tile;
+    const int t = (y / tile) * tiles_x + (x / tile);
+    const int r = t % stride, k = t / stride;
+    const size_t s = (((size_t)r * tpr + k) * tile * tile + (size_t)(y % tile) * tile + (x % tile)) * 3;
+    const size_t d = ((size_t)y * W + x) * 3;
+    dst[d] = src[s]; dst[d + 1] = src[s + 1]; dst[d + 2] = src[s + 2];
+}
+
+// ConvertTo8Bit (src/utils.h:22,34): floor(clamp(x,0,1)*255 + 0.5); rows bottom-up, B,G,R (src/bitmap.cpp:209-217)
+__global__ void quantize_kernel(const float* __restrict__ rgb, uint8_t* __restrict__ out, int W, int H, size_t row_bytes) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    const float* p = rgb + ((size_t)y * W + x) * 3;
+    uint8_t* o = out + (size_t)(H - 1 - y) * row_bytes + (size_t)x * 3;
+    auto q8 = [](float v) { const double c = fmin(fmax((double)v, 0.0), 1.0); return (uint8_t)(int)floor(c * 255.0 + 0.5); };
+    o[0] = q8(p[2]); o[1] = q8(p[1]); o[2] = q8(p[0]);
+}
+
+// ------------------------------------------------------------------------------------------ host side
+thread_local std::string g_err;
+int g_device = -1;
+int g_num_cu = 0;
+bool g_counting = false;
+
+int set_err(const std::string& m) { g_err = m; return -1; }
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+}  // namespace
+
+struct qd_scene {
+    DScene d;
+    std::vector<void*> allocs;
+    uint32_t stack_cap = 0;
+    uint32_t n_lanes = 0;
+    uint64_t* stack = nullptr;
+    uint32_t* queue_ctr = nullptr;       // 8 counters
+    unsigned long long* stats = nullptr; // 8 counters
+    int* error_flag = nullptr;
+    uint32_t spawn0 = 1, spawn1 = 1;     // tasks queued per hit at depth 0 / deeper
+};
+
+namespace {
+
+template <class T>
+int upload(qd_scene* s, const T* src, size_t n, const T** dst) {
+    *dst = nullptr;
+    void* p = nullptr;
+    const size_t bytes = (n ? n : 1) * sizeof(T) + 64;
+    HIP_TRY(hipMalloc(&p, bytes));
+    s->allocs.push_back(p);
+    if (n) HIP_TRY(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *dst = (const T*)p;
+    return 0;
+}
+
+int ensure_stack(qd_scene* s, uint32_t max_depth) {
+    // LIFO bound: each processed task removes one slot and adds at most spawn tasks.
+    const uint64_t cap64 = (uint64_t)s->spawn0 + (uint64_t)s->spawn1 * max_depth + 2;
+    if (cap64 > 4096) return set_err("ray queue bound too large for this scene (samples x depth)");
+    const uint32_t cap = (uint32_t)cap64;
+    if (s->stack && cap <= s->stack_cap) return 0;
+    if (s->stack) { hipFree(s->stack); s->stack = nullptr; }
+    HIP_TRY(hipMalloc((void**)&s->stack, (size_t)cap * kEntryWords * 8 * s->n_lanes));
+    s->stack_cap = cap;
+    return 0;
+}
+
+int launch(qd_scene* s, Params& P, hipStream_t stream) {
+    P.queue_ctr = s->queue_ctr; P.stack = s->stack; P.stack_cap = s->stack_cap; P.n_lanes = s->n_lanes;
+    P.error_flag = s->error_flag;
+    HIP_TRY(hipMemsetAsync(s->queue_ctr, 0, 8 * sizeof(uint32_t), stream));
+    const uint32_t max_blocks = s->n_lanes / 64;
+    const uint32_t grid = P.n_units < max_blocks ? (P.n_units ? P.n_units : 1) : max_blocks;
+    if (g_counting) hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(64), 0, stream, s->d, P);
+    else hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(64), 0, stream, s->d, P);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+void fill_common(Params& P, const qd_camera* cam, const qd_settings* st) {
+    memset(&P, 0, sizeof P);
+    P.cam = *cam;
+    P.W = st->frame_width; P.H = st->frame_height;
+    P.ambient[0] = st->ambient[0]; P.ambient[1] = st->ambient[1]; P.ambient[2] = st->ambient[2];
+    P.max_depth = st->max_trace_depth;
+}
+
+}  // namespace
+
+extern "C" const char* qd_last_error(void) { return g_err.c_str(); }
+
+extern "C" int qd_init(int device) {
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (n <= 0) return set_err("qd_init: no HIP device visible");
+    if (device < 0 || device >= n) return set_err("qd_init: device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    g_device = device;
+    g_num_cu = prop.multiProcessorCount;
+    return 0;
+}
+
+extern "C" void qd_shutdown(void) { g_device = -1; }
+
+extern "C" int qd_set_counting(int on) { g_counting = on != 0; return 0; }
+
+extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
+    if (!desc || !out) return set_err("qd_scene_create: null argument");
+    if (g_device < 0) return set_err("qd_scene_create: qd_init has not been called");
+    *out = nullptr;
+    // validate indices the kernels rely on (a faulting kernel can take the whole GPU down)
+    for (uint32_t i = 0; i < desc->n_geoms; ++i) {
+        const qd_geom& g = desc->geoms[i];
+        if (g.type == QD_GEOM_CSG) {
+            if (g.a < 0 || g.b < 0 || (uint32_t)g.a >= desc->n_geoms || (uint32_t)g.b >= desc->n_geoms) return set_err("qd_scene_create: CSG operand out of range");
+            if (desc->geoms[g.a].type == QD_GEOM_CSG || desc->geoms[g.b].type == QD_GEOM_CSG)
+                return set_err("qd_scene_create: nested CSG operands are not supported by the device path");
+        } else if (g.type == QD_GEOM_MESH) {
+            if (g.a < 0 || (uint32_t)g.a >= desc->n_meshes) return set_err("qd_scene_create: mesh index out of range");
+        } else if (g.type == QD_GEOM_HEIGHTFIELD) {
+            if (g.a < 0 || (uint32_t)g.a >= desc->n_hfields) return set_err("qd_scene_create: heightfield index out of range");
+        } else if (g.type < 0 || g.type > QD_GEOM_HEIGHTFIELD) return set_err("qd_scene_create: unknown geometry type");
+    }
+    for (uint32_t i = 0; i < desc->n_meshes; ++i) {
+        const qd_mesh& m = desc->meshes[i];
+        if ((uint64_t)m.tri_first + m.tri_count > desc->n_tris) return set_err("qd_scene_create: mesh triangle range out of bounds");
+        if (m.kd_root >= 0 && (uint64_t)m.kd_root >= desc->n_kd_nodes) return set_err("qd_scene_create: kd root out of bounds");
+    }
+    for (uint64_t i = 0; i < desc->n_kd_nodes; ++i) {
+        const qd_kdnode& n = desc->kd_nodes[i];
+        const uint64_t idx = n.meta >> 2;
+        if ((n.meta & 3u) == 3u) { if (idx + n.count > desc->n_leaf_tris) return set_err("qd_scene_create: kd leaf range out of bounds"); }
+        else if (idx + 1 >= desc->n_kd_nodes) return set_err("qd_scene_create: kd child out of bounds");
+    }
+    {
+        uint32_t max_tris = 0;
+        for (uint32_t i = 0; i < desc->n_meshes; ++i) max_tris = std::max(max_tris, desc->meshes[i].tri_count);
+        for (uint64_t i = 0; i < desc->n_leaf_tris; ++i)
+            if (desc->leaf_tris[i] >= max_tris) return set_err("qd_scene_create: leaf triangle index out of bounds");
+    }
+    auto tex_ok = [&](int t) { return t >= -1 && t < (int)desc->n_textures; };
+    for (uint32_t i = 0; i < desc->n_textures; ++i) {
+        const qd_texture& t = desc->textures[i];
+        if ((t.type == QD_TEX_BITMAP || t.type == QD_TEX_BUMPMAP) && (t.bitmap < 0 || (uint32_t)t.bitmap >= desc->n_bitmaps)) return set_err("qd_scene_create: texture bitmap out of range");
+        if (t.type == QD_TEX_PROCEDURAL && (t.i0 < 0 || t.i1 < 0 || (uint32_t)(t.i0 + t.i1) > desc->n_proc_lines)) return set_err("qd_scene_create: procedural lines out of range");
+    }
+    for (uint32_t i = 0; i < desc->n_bitmaps; ++i) {
+        const qd_bitmap& b = desc->bitmaps[i];
+        if (b.texel_off + (uint64_t)b.width * b.height > desc->n_texels) return set_err("qd_scene_create: bitmap texels out of range");
+    }
+    uint32_t spawn0 = 1, spawn1 = 1;
+    auto leaf_spawn = [&](const qd_shader& sh, bool deep) -> uint32_t {
+        switch (sh.type) {
+            case QD_SH_LAMBERT: case QD_SH_PHONG: case QD_SH_BLINNPHONG: case QD_SH_ORENNAYAR: return desc->n_lights;
+            case QD_SH_REFL: return sh.p1 == 1 ? 1u : (deep ? 2u : (uint32_t)std::max(sh.i0, 1));
+            case QD_SH_REFR: return 1u;
+            default: return 0u;
+        }
+    };
+    for (uint32_t i = 0; i < desc->n_shaders; ++i) {
+        const qd_shader& sh = desc->shaders[i];
+        if (!tex_ok(sh.tex)) return set_err("qd_scene_create: shader texture out of range");
+        uint32_t s0 = 0, s1 = 0;
+        if (sh.type == QD_SH_LAYERED) {
+            if (sh.i0 < 0 || sh.i1 < 0 || (uint32_t)(sh.i0 + sh.i1) > desc->n_layers) return set_err("qd_scene_create: layer range out of bounds");
+            for (int l = 0; l < sh.i1; ++l) {
+                const qd_layer& ly = desc->layers[sh.i0 + l];
+                if (ly.shader < 0 || (uint32_t)ly.shader >= desc->n_shaders || !tex_ok(ly.tex)) return set_err("qd_scene_create: layer reference out of range");
+                if (desc->shaders[ly.shader].type == QD_SH_LAYERED) return set_err("qd_scene_create: nested Layered shaders are not supported by the device path");
+                s0 += leaf_spawn(desc->shaders[ly.shader], false); s1 += leaf_spawn(desc->shaders[ly.shader], true);
+            }
+        } else { s0 = leaf_spawn(sh, false); s1 = leaf_spawn(sh, true); }
+        spawn0 = std::max(spawn0, s0); spawn1 = std::max(spawn1, s1);
+    }
+    for (uint32_t i = 0; i < desc->n_nodes; ++i) {
+        const qd_node& n = desc->nodes[i];
+        if (n.geom < 0 || (uint32_t)n.geom >= desc->n_geoms || n.shader < 0 || (uint32_t)n.shader >= desc->n_shaders || !tex_ok(n.bump_tex))
+            return set_err("qd_scene_create: node reference out of range");
+    }
+    if (desc->env_present)
+        for (int f = 0; f < 6; ++f)
+            if (desc->env_faces[f] < 0 || (uint32_t)desc->env_faces[f] >= desc->n_bitmaps) return set_err("qd_scene_create: environment face out of range");
+    for (uint32_t i = 0; i < desc->n_hfields; ++i) {
+        const qd_heightfield& h = desc->hfields[i];
+        const uint64_t cells = (uint64_t)h.width * h.height;
+        if (h.heights_off + cells > desc->n_hf_f32 || h.maxheights_off + cells > desc->n_hf_f32 || h.normals_off + cells * 3 > desc->n_hf_f64 ||
+            (h.use_optimization && h.highmap_off + cells * 16 > desc->n_hf_f32) || h.max_k > 16)
+            return set_err("qd_scene_create: heightfield arrays out of range");
+    }
+
+    qd_scene* s = new qd_scene;
+    memset(&s->d, 0, sizeof s->d);
+    DScene& d = s->d;
+    int rc = 0;
+    rc |= upload(s, desc->nodes, desc->n_nodes, &d.nodes);
+    rc |= upload(s, desc->geoms, desc->n_geoms, &d.geoms);
+    rc |= upload(s, desc->meshes, desc->n_meshes, &d.meshes);
+    rc |= upload(s, desc->hfields, desc->n_hfields, &d.hfields);
+    rc |= upload(s, desc->shaders, desc->n_shaders, &d.shaders);
+    rc |= upload(s, desc->layers, desc->n_layers, &d.layers);
+    rc |= upload(s, desc->textures, desc->n_textures, &d.textures);
+    rc |= upload(s, desc->proc_lines, desc->n_proc_lines, &d.proc_lines);
+    rc |= upload(s, desc->bitmaps, desc->n_bitmaps, &d.bitmaps);
+    rc |= upload(s, desc->lights, desc->n_lights, &d.lights);
+    rc |= upload(s, desc->tri_verts, (size_t)desc->n_tris * 9, &d.tri_verts);
+    rc |= upload(s, desc->tri_gnormal, (size_t)desc->n_tris * 3, &d.tri_gnormal);
+    rc |= upload(s, desc->tri_shade, (size_t)desc->n_tris * 21, &d.tri_shade);
+    rc |= upload(s, desc->kd_nodes, (size_t)desc->n_kd_nodes, &d.kd_nodes);
+    rc |= upload(s, desc->leaf_tris, (size_t)desc->n_leaf_tris, &d.leaf_tris);
+    rc |= upload(s, desc->texels, (size_t)desc->n_texels * 3, &d.texels);
+    rc |= upload(s, desc->hf_f32, (size_t)desc->n_hf_f32, &d.hf_f32);
+    rc |= upload(s, desc->hf_f64, (size_t)desc->n_hf_f64, &d.hf_f64);
+    d.n_nodes = desc->n_nodes; d.n_lights = desc->n_lights;
+    d.env_present = desc->env_present; d.env_bilinear = desc->env_bilinear;
+    for (int f = 0; f < 6; ++f) d.env_faces[f] = desc->env_faces[f];
+    s->spawn0 = spawn0; s->spawn1 = spawn1;
+    s->n_lanes = (uint32_t)(g_num_cu > 0 ? g_num_cu : 256) * 8u * 64u;
+    if (!rc && hipMalloc((void**)&s->queue_ctr, 8 * sizeof(uint32_t)) != hipSuccess) rc = set_err("hipMalloc(queue counters) failed");
+    if (!rc && hipMalloc((void**)&s->stats, 8 * sizeof(unsigned long long)) != hipSuccess) rc = set_err("hipMalloc(stats) failed");
+    if (!rc && hipMalloc((void**)&s->error_flag, sizeof(int)) != hipSuccess) rc = set_err("hipMalloc(error flag) failed");
+    if (!rc && hipMemset(s->error_flag, 0, sizeof(int)) != hipSuccess) rc = set_err("hipMemset failed");
+    if (!rc) rc = ensure_stack(s, desc->settings.max_trace_depth);
+    if (rc) { qd_scene_destroy(s); return -1; }
+    *out = s;
+    return 0;
+}
+
+extern "C" void qd_scene_destroy(qd_scene* s) {
+    if (!s) return;
+    for (void* p : s->allocs) hipFree(p);
+    if (s->stack) hipFree(s->stack);
+    if (s->queue_ctr) hipFree(s->queue_ctr);
+    if (s->stats) hipFree(s->stats);
+    if (s->error_flag) hipFree(s->error_flag);
+    delete s;
+}
+
+extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* st, int x0, int y0, int x1, int y1,
+                         float* rgb, size_t pitch, int32_t* hit_node, int32_t* hit_tri, double* hit_dist, qd_stats* stats) {
+    if (!s || !cam || !st || !rgb) return set_err("qd_render: null argument");
+    if (x1 <= x0 || y1 <= y0 || x0 < 0 || y0 < 0 || x1 > st->frame_width || y1 > st->frame_height) return set_err("qd_render: bad rectangle");
+    if ((hit_node || hit_tri || hit_dist) && !(hit_node && hit_tri && hit_dist)) return set_err("qd_render: hit outputs must be all set or all NULL");
+    const int rw = x1 - x0, rh = y1 - y0;
+    if (pitch < (size_t)rw * 3) return set_err("qd_render: row pitch smaller than the rectangle");
+    if (ensure_stack(s, st->max_trace_depth)) return -1;
+    Params P; fill_common(P, cam, st);
+    P.mode = 0; P.x0 = x0; P.y0 = y0; P.rw = rw; P.rh = rh;
+    P.units_x = (uint32_t)(rw + 7) / 8;
+    P.n_units = P.units_x * (uint32_t)((rh + 7) / 8);
+    const size_t npx = (size_t)rw * rh;
+    float* d_rgb = nullptr; int32_t* d_hn = nullptr; int32_t* d_ht = nullptr; double* d_hd = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() {
+        if (d_rgb) hipFree(d_rgb); if (d_hn) hipFree(d_hn); if (d_ht) hipFree(d_ht); if (d_hd) hipFree(d_hd);
+        if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1);
+    };
+#define TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return -1; } } while (0)
+    TRY2(hipMalloc((void**)&d_rgb, npx * 3 * sizeof(float)));
+    if (hit_node) {
+        TRY2(hipMalloc((void**)&d_hn, npx * sizeof(int32_t)));
+        TRY2(hipMalloc((void**)&d_ht, npx * sizeof(int32_t)));
+        TRY2(hipMalloc((void**)&d_hd, npx * sizeof(double)));
+    }
+    P.rgb = d_rgb; P.pitch = (size_t)rw * 3; P.hit_node = d_hn; P.hit_tri = d_ht; P.hit_dist = d_hd;
+    P.stats = s->stats;
+    TRY2(hipMemsetAsync(s->stats, 0, 8 * sizeof(unsigned long long), nullptr));
+    TRY2(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
+    TRY2(hipEventCreate(&e0)); TRY2(hipEventCreate(&e1));
+    TRY2(hipEventRecord(e0, nullptr));
+    rc = launch(s, P, nullptr);
+    if (rc) { cleanup(); return -1; }
+    TRY2(hipEventRecord(e1, nullptr));
+    TRY2(hipEventSynchronize(e1));
+    float ms = 0; TRY2(hipEventElapsedTime(&ms, e0, e1));
+    int err_flag = 0;
+    TRY2(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (err_flag) { cleanup(); return set_err("qd_render: ray queue overflow on device"); }
+    TRY2(hipMemcpy2D(rgb, pitch * sizeof(float), d_rgb, (size_t)rw * 3 * sizeof(float), (size_t)rw * 3 * sizeof(float), rh, hipMemcpyDeviceToHost));
+    if (hit_node) {
+        TRY2(hipMemcpy(hit_node, d_hn, npx * sizeof(int32_t), hipMemcpyDeviceToHost));
+        TRY2(hipMemcpy(hit_tri, d_ht, npx * sizeof(int32_t), hipMemcpyDeviceToHost));
+        TRY2(hipMemcpy(hit_dist, d_hd, npx * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (stats) {
+        unsigned long long h[8];
+        TRY2(hipMemcpy(h, s->stats, sizeof h, hipMemcpyDeviceToHost));
+        stats->rays = h[0]; stats->primary_rays = h[1]; stats->shadow_rays = h[2]; stats->depth_killed = h[3];
+        stats->kd_nodes_visited = h[4]; stats->tris_tested = h[5]; stats->mesh_queries = h[6];
+        stats->kernel_ms = ms;
+    }
+    cleanup();
+#undef TRY2
+    return 0;
+}
+
+extern "C" int qd_render_tiles_async(qd_scene* s, const qd_camera* cam, const qd_settings* st, int tile, int tile_phase,
+                                     int tile_stride, float* rgb_dev, qd_stats* stats_dev, void* hip_stream) {
+    if (!s || !cam || !st || !rgb_dev) return set_err("qd_render_tiles_async: null argument");
+    if (tile < 8 || tile % 8 || tile_stride < 1 || tile_phase < 0 || tile_phase >= tile_stride) return set_err("qd_render_tiles_async: bad tiling");
+    if (ensure_stack(s, st->max_trace_depth)) return -1;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    Params P; fill_common(P, cam, st);
+    P.mode = 1; P.tile = tile; P.phase = tile_phase; P.stride = tile_stride;
+    P.tiles_x = (st->frame_width + tile - 1) / tile;
+    const int tiles_y = (st->frame_height + tile - 1) / tile;
+    const int n_tiles = P.tiles_x * tiles_y;
+    const int n_owned = n_tiles > tile_phase ? (n_tiles - tile_phase + tile_stride - 1) / tile_stride : 0;
+    P.n_units = (uint32_t)n_owned * (uint32_t)((tile / 8) * (tile / 8));
+    P.rgb = rgb_dev;
+    P.stats = (unsigned long long*)stats_dev;   // first 7 fields of qd_stats are the 64-bit counters
+    if (stats_dev) HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(qd_stats), stream));
+    if (P.n_units == 0) return 0;
+    return launch(s, P, stream);
+}
+
+extern "C" int qd_untile_async(const float* src_dev, float* dst_dev, int width, int height, int tile, int tile_stride,
+                               int tiles_per_rank_padded, void* hip_stream) {
+    if (!src_dev || !dst_dev || width <= 0 || height <= 0 || tile < 8 || tile_stride < 1) return set_err("qd_untile_async: bad argument");
+    hipLaunchKernelGGL(untile_kernel, dim3((width + 255) / 256, height), dim3(256), 0, (hipStream_t)hip_stream, src_dev, dst_dev, width, height,
+                       tile, tile_stride, tiles_per_rank_padded);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int qd_quantize_bgr8_async(const float* rgb_dev, uint8_t* bgr_dev, int width, int height, size_t row_bytes, void* hip_stream) {
+    if (!rgb_dev || !bgr_dev || width <= 0 || height <= 0 || row_bytes < (size_t)width * 3) return set_err("qd_quantize_bgr8_async: bad argument");
+    hipLaunchKernelGGL(quantize_kernel, dim3((width + 255) / 256, height), dim3(256), 0, (hipStream_t)hip_stream, rgb_dev, bgr_dev, width, height, row_bytes);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Device error flag of the last asynchronous launches on this scene (ray queue overflow): 0 = fine.
+extern "C" int qd_scene_check(qd_scene* s) {
+    if (!s) return set_err("qd_scene_check: null scene");
+    int f = 0;
+    HIP_TRY(hipMemcpy(&f, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (f) { hipMemset(s->error_flag, 0, sizeof(int)); return set_err("ray queue overflow on device"); }
+    return 0;
+}

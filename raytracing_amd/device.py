@@ -1,0 +1,122 @@
+"""Python face of the HIP trace library (libqdtrace.so).  No fallback: a missing library or GPU is an error."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_INIT_DEVICE = None
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "lib", "libqdtrace.so")
+        if not os.path.exists(path):
+            raise DeviceError(f"{path} is missing: the HIP extension was not built (python -m raytracing_amd.build device)")
+        L = C.CDLL(path)
+        P = C.POINTER
+        L.qd_last_error.restype = C.c_char_p
+        L.qd_init.argtypes = [C.c_int]
+        L.qd_set_counting.argtypes = [C.c_int]
+        L.qd_scene_create.argtypes = [P(abi.QdSceneDesc), P(C.c_void_p)]
+        L.qd_scene_destroy.argtypes = [C.c_void_p]
+        L.qd_scene_check.argtypes = [C.c_void_p]
+        L.qd_render.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, P(abi.QdStats)]
+        L.qd_render_tiles_async.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
+        L.qd_untile_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.qd_quantize_bgr8_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
+        for name in abi.QDTRACE_SYMBOLS:
+            if name not in ("qd_last_error", "qd_shutdown", "qd_scene_destroy"):
+                getattr(L, name).restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise DeviceError(f"{what}: {lib().qd_last_error().decode()}")
+
+
+def init(device=0):
+    global _INIT_DEVICE
+    _check(lib().qd_init(device), "qd_init")
+    _INIT_DEVICE = device
+
+
+def set_counting(on):
+    _check(lib().qd_set_counting(1 if on else 0), "qd_set_counting")
+
+
+class DeviceScene:
+    """Scene buffers resident in HBM (qd_scene_create)."""
+
+    def __init__(self, scene):
+        if _INIT_DEVICE is None:
+            init(0)
+        self.host_scene = scene
+        h = C.c_void_p()
+        _check(lib().qd_scene_create(scene.desc_ptr, C.byref(h)), "qd_scene_create")
+        self._h = h
+
+    def render(self, x0=0, y0=0, x1=None, y1=None, camera=None, settings=None, hits=False):
+        st = settings if settings is not None else self.host_scene.settings
+        cam = camera if camera is not None else self.host_scene.camera
+        x1 = st.frame_width if x1 is None else x1
+        y1 = st.frame_height if y1 is None else y1
+        w, h = x1 - x0, y1 - y0
+        rgb = np.zeros((h, w, 3), np.float32)
+        hn = np.full((h, w), -2, np.int32) if hits else None
+        ht = np.full((h, w), -2, np.int32) if hits else None
+        hd = np.zeros((h, w), np.float64) if hits else None
+        stats = abi.QdStats()
+        _check(lib().qd_render(self._h, C.byref(cam), C.byref(st), x0, y0, x1, y1, rgb.ctypes.data, w * 3,
+                               hn.ctypes.data if hits else None, ht.ctypes.data if hits else None,
+                               hd.ctypes.data if hits else None, C.byref(stats)), "qd_render")
+        return rgb, ((hn, ht, hd) if hits else None), stats.as_dict()
+
+    def render_tiles_async(self, rgb_dev_ptr, tile, phase, stride, stats_dev_ptr=None, stream=None,
+                           camera=None, settings=None):
+        st = settings if settings is not None else self.host_scene.settings
+        cam = camera if camera is not None else self.host_scene.camera
+        _check(lib().qd_render_tiles_async(self._h, C.byref(cam), C.byref(st), tile, phase, stride,
+                                           C.c_void_p(rgb_dev_ptr), C.c_void_p(stats_dev_ptr or 0),
+                                           C.c_void_p(stream or 0)), "qd_render_tiles_async")
+
+    def check(self):
+        _check(lib().qd_scene_check(self._h), "qd_scene_check")
+
+    def close(self):
+        if self._h:
+            lib().qd_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def untile_async(src_ptr, dst_ptr, width, height, tile, stride, tiles_per_rank_padded, stream=None):
+    _check(lib().qd_untile_async(C.c_void_p(src_ptr), C.c_void_p(dst_ptr), width, height, tile, stride,
+                                 tiles_per_rank_padded, C.c_void_p(stream or 0)), "qd_untile_async")
+
+
+def quantize_bgr8_async(rgb_ptr, out_ptr, width, height, row_bytes, stream=None):
+    _check(lib().qd_quantize_bgr8_async(C.c_void_p(rgb_ptr), C.c_void_p(out_ptr), width, height, row_bytes,
+                                        C.c_void_p(stream or 0)), "qd_quantize_bgr8_async")
+
+
+def tiles_owned(width, height, tile, phase, stride):
+    n_tiles = ((width + tile - 1) // tile) * ((height + tile - 1) // tile)
+    return (n_tiles - phase + stride - 1) // stride if n_tiles > phase else 0

@@ -1,0 +1,45 @@
+"""Exploratory GPU-vs-oracle comparison over the fixture scenes (development aid, not a test)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+from raytracing_amd import device, host  # noqa: E402
+
+D = os.path.join(ROOT, "tests", "golden", "data")
+scenes = sys.argv[1:] or ["hw9/nonconvex.qdmg", "window_fixed.qdmg", "bumpmap_fixed.qdmg", "lecture7_fixed.qdmg",
+                          "heightfield_fixed.qdmg", "kdtree_teapot_lowres_env.qdmg", "kdtree_fixed.qdmg"]
+device.init(0)
+device.set_counting(True)
+out = {}
+for name in scenes:
+    s = host.Scene.load(os.path.join(D, name))
+    s.settings.want_aa = 0
+    W, H = s.settings.frame_width, s.settings.frame_height
+    ds = device.DeviceScene(s)
+    t = time.time()
+    rgb, (hn, ht, hd), st = ds.render(hits=True)
+    t_gpu = time.time() - t
+    t = time.time()
+    orgb, (ohn, oht, ohd), ost = oracle.render_rect(s, 0, 0, W, H, hits=True, rng_mode=1, threads=16)
+    t_cpu = time.time() - t
+    err = np.abs(rgb.astype(np.float64) - orgb.astype(np.float64)).max(axis=2)
+    res = {
+        "W": W, "H": H, "gpu_s": round(t_gpu, 3), "kernel_ms": round(st["kernel_ms"], 3), "cpu_s": round(t_cpu, 2),
+        "node_mismatch": int((hn != ohn).sum()), "tri_mismatch": int((ht != oht).sum()),
+        "dist_bit_mismatch": int((hd.view(np.uint64) != ohd.view(np.uint64)).sum()),
+        "dist_max_rel": float(np.max(np.abs(hd - ohd) / np.maximum(np.abs(ohd), 1e-300))) if (ohd != 0).any() else 0.0,
+        "max_err": float(err.max()), "px_gt_1e-4": int((err > 1e-4).sum()), "px_gt_1e-3": int((err > 1e-3).sum()),
+        "nan_gpu": int(np.isnan(rgb).sum()), "nan_cpu": int(np.isnan(orgb).sum()),
+        "gpu_stats": {k: v for k, v in st.items()}, "cpu_stats": ost,
+    }
+    out[name] = res
+    print(name, json.dumps(res), flush=True)
+    ds.close()
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "explore.json"), "w"), indent=1)
