@@ -1,0 +1,44 @@
+"""Tile ownership for multi-GPU frames (pure index math, no GPU needed).
+
+The frame is cut into `tile` x `tile` squares numbered row-major (the reference walks 48x48 buckets,
+src/sdl.cpp:253-276; pixels are independent, so any partition renders the same image).  Rank r of
+`world` owns tiles t with t % world == r and stores them compacted in increasing t; every rank's
+block is padded to the same number of tiles so one equal-size gather moves the framebuffer.
+"""
+import numpy as np
+
+
+def tile_grid(width, height, tile):
+    return (width + tile - 1) // tile, (height + tile - 1) // tile
+
+
+def tiles_owned(width, height, tile, rank, world):
+    tx, ty = tile_grid(width, height, tile)
+    n = tx * ty
+    return (n - rank + world - 1) // world if n > rank else 0
+
+
+def tiles_per_rank_padded(width, height, tile, world):
+    return tiles_owned(width, height, tile, 0, world)
+
+
+def owned_tile_rects(width, height, tile, rank, world):
+    """[(x0, y0, x1, y1)] of the tiles a rank owns, in storage order (clipped to the frame)."""
+    tx, ty = tile_grid(width, height, tile)
+    out = []
+    for t in range(rank, tx * ty, world):
+        x0, y0 = (t % tx) * tile, (t // tx) * tile
+        out.append((x0, y0, min(x0 + tile, width), min(y0 + tile, height)))
+    return out
+
+
+def untile(gathered, width, height, tile, world):
+    """CPU mirror of qd_untile_async: gathered[world, tiles_padded, tile, tile, 3] -> image[H, W, 3]."""
+    gathered = np.asarray(gathered)
+    tpr = gathered.shape[1]
+    img = np.zeros((height, width, 3), gathered.dtype)
+    for r in range(world):
+        for k, (x0, y0, x1, y1) in enumerate(owned_tile_rects(width, height, tile, r, world)):
+            assert k < tpr
+            img[y0:y1, x0:x1] = gathered[r, k, : y1 - y0, : x1 - x0]
+    return img

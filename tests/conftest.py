@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+DATA = os.path.join(ROOT, "tests", "golden", "data")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def data_dir():
+    return DATA
+
+
+@pytest.fixture(scope="session")
+def load_scene():
+    from raytracing_amd import host
+
+    cache = {}
+
+    def _load(name):
+        if name not in cache:
+            cache[name] = host.Scene.load(os.path.join(DATA, name))
+        return cache[name]
+
+    return _load

@@ -1,0 +1,162 @@
+"""GPU parity: the HIP path, called through the C-ABI, against the CPU oracle on the same scenes.
+
+Bar (BASELINE.json north_star): primary-ray hit node / triangle IDs bit-exact except documented
+near-tie rays (< 0.01 % of pixels); per-channel colour error <= 1e-4 absolute (pixels whose
+secondary rays took a different discrete branch are counted with the near-ties, same 0.01 % budget).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from raytracing_amd import device, host, sharding
+
+pytestmark = pytest.mark.gpu
+
+COLOUR_TOL = 1e-4
+NEAR_TIE_BUDGET = 1e-4     # 0.01 % of pixels
+
+SCENES = ["hw9/nonconvex.qdmg", "window_fixed.qdmg", "bumpmap_fixed.qdmg", "lecture7_fixed.qdmg",
+          "heightfield_fixed.qdmg", "kdtree_teapot_lowres_env.qdmg", "kdtree_teapot_hires_sah_noenv.qdmg",
+          "kdtree_fixed.qdmg"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    device.init(0)
+    yield
+
+
+def compare(s, ds, x0, y0, x1, y1):
+    rgb, (hn, ht, hd), st = ds.render(x0, y0, x1, y1, hits=True)
+    orgb, (ohn, oht, ohd), ost = oracle.render_rect(s, x0, y0, x1, y1, hits=True, rng_mode=1, threads=16)
+    n = hn.size
+    id_mismatch = int(((hn != ohn) | (ht != oht)).sum())
+    dist_mismatch = int((hd.view(np.uint64) != ohd.view(np.uint64)).sum())
+    err = np.abs(rgb.astype(np.float64) - orgb.astype(np.float64)).max(axis=2)
+    bad = int((~(err <= COLOUR_TOL)).sum())      # NaN counts as bad
+    return dict(n=n, id_mismatch=id_mismatch, dist_mismatch=dist_mismatch, bad_colour=bad, max_err=float(np.nanmax(err)),
+                gpu=st, cpu=ost, rgb=rgb, orgb=orgb)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_scene_matches_oracle(load_scene, name):
+    s = load_scene(name)
+    s.settings.want_aa = 0
+    W, H = s.settings.frame_width, s.settings.frame_height
+    ds = device.DeviceScene(s)
+    try:
+        r = compare(s, ds, 0, 0, W, H)
+    finally:
+        ds.close()
+    budget = max(1, int(r["n"] * NEAR_TIE_BUDGET))
+    assert r["id_mismatch"] <= budget, r["id_mismatch"]
+    assert r["dist_mismatch"] <= budget, r["dist_mismatch"]
+    assert r["bad_colour"] <= budget, (r["bad_colour"], r["max_err"])
+    # the ray population is the reference's: same number of traced radiance + shadow rays (near-ties aside)
+    assert abs(r["gpu"]["rays"] - r["cpu"]["rays"]) <= max(16, r["cpu"]["rays"] * 1e-5)
+    assert r["gpu"]["depth_killed"] == pytest.approx(r["cpu"]["depth_killed"], abs=16)
+    assert r["gpu"]["primary_rays"] == r["n"]
+
+
+def test_synthetic_mesh_scene_matches_oracle(data_dir):
+    s = host.Scene.synthetic(96, seed=42, width=320, height=180, max_trace_depth=8,
+                             env_folder=os.path.join(data_dir, "env", "forest"))
+    ds = device.DeviceScene(s)
+    try:
+        r = compare(s, ds, 0, 0, 320, 180)
+    finally:
+        ds.close()
+    assert r["id_mismatch"] <= 5 and r["dist_mismatch"] <= 5 and r["bad_colour"] <= 5, (r["id_mismatch"], r["bad_colour"], r["max_err"])
+    assert r["gpu"]["rays"] > 2 * r["n"]      # glass: secondary + shadow rays are really traced
+
+
+def test_ragged_rectangles_and_pitch(load_scene):
+    s = load_scene("window_fixed.qdmg")
+    s.settings.want_aa = 0
+    ds = device.DeviceScene(s)
+    try:
+        full, _, _ = ds.render()
+        for (x0, y0, x1, y1) in [(0, 0, 1, 1), (5, 7, 6, 20), (633, 471, 640, 480), (100, 100, 173, 131)]:
+            part, hits, st = ds.render(x0, y0, x1, y1, hits=True)
+            assert np.array_equal(part, full[y0:y1, x0:x1])
+            assert st["primary_rays"] == (x1 - x0) * (y1 - y0)
+        with pytest.raises(device.DeviceError):
+            ds.render(10, 10, 10, 20)            # empty rectangle is rejected, like a bad bucket
+        with pytest.raises(device.DeviceError):
+            ds.render(0, 0, 641, 480)
+    finally:
+        ds.close()
+
+
+def test_tile_sharded_frame_equals_single_rectangle(load_scene):
+    """render(N shards) == render(1 GPU) bytewise: pixels are independent."""
+    import torch
+    s = load_scene("heightfield_fixed.qdmg")
+    s.settings.want_aa = 0
+    W, H = s.settings.frame_width, s.settings.frame_height
+    ds = device.DeviceScene(s)
+    try:
+        full, _, _ = ds.render()
+        tile = 32
+        for world in (1, 3):
+            tpr = sharding.tiles_per_rank_padded(W, H, tile, world)
+            gathered = torch.zeros((world, tpr, tile, tile, 3), dtype=torch.float32, device="cuda:0")
+            for r in range(world):
+                ds.render_tiles_async(gathered[r].data_ptr(), tile, r, world)
+            frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+            device.untile_async(gathered.data_ptr(), frame.data_ptr(), W, H, tile, world, tpr)
+            torch.cuda.synchronize()
+            ds.check()
+            assert np.array_equal(frame.cpu().numpy(), full)
+            assert np.array_equal(sharding.untile(gathered.cpu().numpy(), W, H, tile, world), full)
+    finally:
+        ds.close()
+
+
+def test_4k_heightfield_properties(load_scene):
+    """BASELINE config 4 at 3840x2160: too big for a full oracle frame in seconds, so check
+    size-independent properties: a strided pixel sample against the oracle, run-to-run determinism."""
+    s = load_scene("heightfield_fixed.qdmg")
+    st = s.settings
+    old = (st.frame_width, st.frame_height, st.want_aa)
+    st.frame_width, st.frame_height, st.want_aa = 3840, 2160, 0
+    ds = device.DeviceScene(s)
+    try:
+        a, _, sa = ds.render()
+        b, _, sb = ds.render()
+        assert np.array_equal(a, b) and sa["rays"] == sb["rays"]
+        ys, xs = np.meshgrid(np.arange(3, 2160, 29), np.arange(5, 3840, 31), indexing="ij")
+        xy = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
+        orgb, _, _ = oracle.render_pixels(s, xy, rng_mode=1, threads=16)
+        err = np.abs(a[xy[:, 1], xy[:, 0]].astype(np.float64) - orgb).max(axis=1)
+        assert (~(err <= COLOUR_TOL)).sum() <= max(1, int(len(xy) * 2 * NEAR_TIE_BUDGET)), err.max()
+    finally:
+        ds.close()
+        st.frame_width, st.frame_height, st.want_aa = old
+
+
+def test_quantize_kernel_matches_convert_to_8bit():
+    import torch
+    rng = np.random.default_rng(3)
+    img = (rng.random((37, 53, 3), dtype=np.float32) * 1.4 - 0.2)
+    img[0, 0] = [0.5, 1.0, 0.0]
+    t = torch.from_numpy(img).cuda()
+    row_bytes = (53 * 3 + 3) // 4 * 4
+    out = torch.zeros((37, row_bytes), dtype=torch.uint8, device="cuda:0")
+    device.quantize_bgr8_async(t.data_ptr(), out.data_ptr(), 53, 37, row_bytes)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()[:, :53 * 3].reshape(37, 53, 3)
+    exp = np.floor(np.clip(img.astype(np.float64), 0, 1) * 255 + 0.5).astype(np.uint8)[::-1, :, ::-1]   # bottom-up, BGR
+    assert np.array_equal(got, exp)
+    assert oracle.lib().orc_convert_to_8bit(0.5) == got[36, 0, 2]
+
+
+def test_nested_layered_and_csg_are_rejected_loudly(tmp_path):
+    p = tmp_path / "n.qdmg"
+    p.write_text("Camera c {\n position (0,0,-5)\n}\nSphere s {\n}\nConst k {\n}\nLayered a {\n layer k (1,1,1)\n}\n"
+                 "Layered b {\n layer a (1,1,1)\n}\nNode n {\n geometry s\n shader b\n}\n")
+    s = host.Scene.load(str(p))
+    with pytest.raises(device.DeviceError, match="nested Layered"):
+        device.DeviceScene(s)

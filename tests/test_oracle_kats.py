@@ -1,0 +1,92 @@
+"""Pins the CPU oracle to outputs of the unmodified reference (tests/golden/reference_kats.json):
+whole-frame md5 of the raw float framebuffer, ray counts, spot pixels, per-ray box / triangle test
+averages.  If these hold, the oracle IS the reference's render, bit for bit, on these scenes."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KATS = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kats.json")))
+
+_frames = {}
+
+
+def frame(load_scene, name):
+    if name not in _frames:
+        _frames[name] = oracle.render_frame(load_scene(name), rng_mode=0)   # libc rand() like the reference
+    return _frames[name]
+
+
+@pytest.mark.parametrize("name", sorted(KATS["frame_md5"]))
+def test_frame_md5_matches_the_reference(load_scene, name):
+    rgb, stats = frame(load_scene, name)
+    assert hashlib.md5(rgb.tobytes()).hexdigest() == KATS["frame_md5"][name]
+
+
+@pytest.mark.parametrize("name", sorted(KATS["ray_counts"]))
+def test_ray_counts_match_the_reference(load_scene, name):
+    _, stats = frame(load_scene, name)
+    for k, v in KATS["ray_counts"][name].items():
+        assert stats[k] == v, k
+
+
+def test_spot_pixels(load_scene):
+    rgb, _ = frame(load_scene, "hw9/nonconvex.qdmg")
+    for key, exp in KATS["spot_pixels_hex"]["hw9/nonconvex.qdmg"].items():
+        x, y = map(int, key.split(","))
+        assert [float(v) for v in rgb[y, x]] == [float.fromhex(h) for h in exp]
+
+
+@pytest.mark.parametrize("name", ["kdtree_teapot_lowres_noenv.qdmg", "kdtree_teapot_hires_sah_noenv.qdmg"])
+def test_box_and_triangle_tests_per_mesh_ray(load_scene, name):
+    # the reference prints nbBBoxIntersections/nbIntersections and nbTriIntersections/nbIntersections (src/mesh.cpp:194-195)
+    _, stats = frame(load_scene, name)
+    exp = KATS["kd_stats"][name]
+    assert round(stats["bbox_tests"] / stats["mesh_queries"], 6) == pytest.approx(exp["avg_bbox_tests"], abs=5e-7)
+    assert round(stats["tri_tests"] / stats["mesh_queries"], 6) == pytest.approx(exp["avg_tri_tests"], abs=5e-7)
+
+
+def test_1low_counters_via_the_full_config_scene(load_scene):
+    _, stats = frame(load_scene, "kdtree_fixed.qdmg")   # environment does not change the mesh counters
+    exp = KATS["kd_stats"]["kdtree_1low_noenv.qdmg"]
+    assert round(stats["bbox_tests"] / stats["mesh_queries"], 6) == pytest.approx(exp["avg_bbox_tests"], abs=5e-7)
+    assert round(stats["tri_tests"] / stats["mesh_queries"], 6) == pytest.approx(exp["avg_tri_tests"], abs=5e-7)
+
+
+def test_threads_and_rect_api_agree_with_frame_render(load_scene):
+    s = load_scene("window_fixed.qdmg")
+    full, _ = frame(load_scene, "window_fixed.qdmg")     # AA is off in the fixed scene, no glossy: rng-independent
+    rect, hits, _ = oracle.render_rect(s, 100, 50, 300, 200, hits=True, rng_mode=1, threads=4)
+    assert np.array_equal(rect, full[50:200, 100:300])
+    xy = np.array([[100, 50], [299, 199], [0, 0]], np.int32)
+    px, _, _ = oracle.render_pixels(s, xy, rng_mode=1, threads=2)
+    assert np.array_equal(px[0], full[50, 100]) and np.array_equal(px[1], full[199, 299]) and np.array_equal(px[2], full[0, 0])
+    hn, ht, hd = hits
+    assert hn.min() >= -1 and (ht == -1).all() and (hd[hn >= 0] > 0).all()
+
+
+def test_kd_walk_equals_brute_force(load_scene, tmp_path, data_dir):
+    # the recursive box-gated walk returns exactly the brute-force closest hit
+    from raytracing_amd import host
+    src = open(os.path.join(data_dir, "kdtree_teapot_lowres_noenv.qdmg")).read().replace("useKDTree true", "useKDTree false")
+    p = os.path.join(data_dir, "_tmp_nokd.qdmg")
+    open(p, "w").write(src)
+    try:
+        brute = host.Scene.load(p)
+    finally:
+        os.remove(p)
+    kd = load_scene("kdtree_teapot_lowres_noenv.qdmg")
+    assert brute.desc.meshes[0].kd_root == -1 and kd.desc.meshes[0].kd_root >= 0
+    a, ha, _ = oracle.render_rect(kd, 400, 300, 800, 600, hits=True, threads=8)
+    b, hb, _ = oracle.render_rect(brute, 400, 300, 800, 600, hits=True, threads=8)
+    assert np.array_equal(ha[0], hb[0]) and np.array_equal(ha[1], hb[1]) and np.array_equal(ha[2].view(np.uint64), hb[2].view(np.uint64))
+    assert np.array_equal(a, b)
+
+
+def test_quantisation():
+    assert [oracle.lib().orc_convert_to_8bit(v) for v in (-1.0, 0.0, 0.5, 0.999, 1.0, 7.0)] == [0, 0, 128, 255, 255, 255]
