@@ -135,11 +135,13 @@ QD_DEV bool mesh_intersect(const DScene& S, int mesh_idx, const DV& o, const DV&
                 const uint32_t left = n.meta >> 2;
                 const double oa = comp(o, (int)axis);
                 const double t = (n.split - oa) * inv[axis];
-                const bool right_first = oa > n.split;                  // src/mesh.cpp:75-77
+                // near child = the side the origin is on (src/mesh.cpp:75-77: right iff start > split); an origin
+                // exactly on the plane belongs to the side the ray travels into.  The sign of t is exact.
+                const bool right_first = oa > n.split || (oa == n.split && comp(d, (int)axis) > 0);
                 const uint32_t near_c = left + (right_first ? 1u : 0u), far_c = left + (right_first ? 0u : 1u);
                 const double slack = 1e-7 + 1e-9 * fabs(t);
-                if (t > tmax + slack || t < -slack) {
-                    node = near_c;                                      // plane beyond the interval or behind the origin
+                if (t > tmax + slack || t <= 0) {
+                    node = near_c;                                      // plane beyond the interval, or at/behind the origin
                 } else if (t < tmin - slack) {
                     node = far_c;                                       // crossed before the interval starts
                 } else {                                                // (also taken when t is NaN: ray inside the plane)

@@ -177,8 +177,10 @@ extern "C" qdh_scene* qdh_synth_scene(int n, unsigned seed, int width, int heigh
     st.frame_width = width; st.frame_height = height;
     st.ambient[0] = st.ambient[1] = st.ambient[2] = 0.25f;
     st.want_aa = 0; st.want_adaptive_aa = 0; st.max_trace_depth = (uint32_t)max_trace_depth;
-    const double cam_pos[3] = {0, 70, -140};
-    qdh_camera_corners(cam_pos, 0., -25., 0., 90., 1.7778, &S.desc.camera);
+    // slightly off-axis on purpose: a camera in the x = 0 plane would shoot a whole pixel column exactly along
+    // shared triangle edges and KD split planes (exact-tie rays)
+    const double cam_pos[3] = {7.3, 70, -140};
+    qdh_camera_corners(cam_pos, 3., -25., 0., 90., 1.7778, &S.desc.camera);
 
     if (env_folder && env_folder[0]) {
         std::string err;
