@@ -53,21 +53,31 @@ struct GHit {
 
 struct Counters { uint32_t kd_nodes, tris, mesh_queries; };
 
-constexpr int kKdStack = 72;   // MAX_TREE_DEPTH 64 -> leaves at depth <= 65 (src/constants.h:13, src/mesh.cpp:218)
+constexpr int kKdStack = 72;
+
+// KD node as one 16-byte load (hipMalloc'd arrays are 256-byte aligned, nodes are 16 bytes)
+struct KdNode { double split; uint32_t meta, count; };
+QD_DEV KdNode ld_kdnode(const DScene& S, uint32_t i) {
+    const uint4 v = reinterpret_cast<const uint4*>(S.kd_nodes)[i];
+    KdNode n;
+    n.split = __hiloint2double((int)v.y, (int)v.x);
+    n.meta = v.z; n.count = v.w;
+    return n;
+}   // MAX_TREE_DEPTH 64 -> leaves at depth <= 65 (src/constants.h:13, src/mesh.cpp:218)
 
 // ---------------------------------------------------------------- mesh: triangle test
 // Mesh::Intersect(ray, triangle, info), src/mesh.cpp:111-168.  Returns true when the triangle
 // replaces the running hit.  The three quotients are only formed once the sign tests (which are
 // exact consequences of `gamma < 0`, `lambda2 < 0`, `lambda3 < 0`) have passed.
 template <bool STATS>
-QD_DEV bool tri_test(const DScene& S, const qd_mesh& m, uint32_t local, const DV& o, const DV& d, const DV& md,
+QD_DEV bool tri_test(const DScene& S, uint32_t flags, uint32_t tri_first, uint32_t local, const DV& o, const DV& d, const DV& md,
                      double& best, double& l2o, double& l3o, Counters& cnt) {
-    const size_t t = (size_t)m.tri_first + local;
+    const size_t t = (size_t)tri_first + local;
     const double* tv = S.tri_verts + t * 9;
     const DV A = ld3(tv), AB = ld3(tv + 3), AC = ld3(tv + 6);
     const DV N = cross(AB, AC);
     const double dcr = dot(N, md);                 // Det(AB, AC, -D)
-    if (m.flags & QD_MESH_BACKCULL) {
+    if (flags & QD_MESH_BACKCULL) {
         // reference: ray.dir * geometryNormal > 0 with geometryNormal = N * (1/|N|).  dir.N == -dcr exactly;
         // its sign equals the sign of dir.gnormal unless the product is within rounding of zero, where the
         // stored unit normal decides.
@@ -95,31 +105,44 @@ QD_DEV bool tri_test(const DScene& S, const qd_mesh& m, uint32_t local, const DV
     return true;
 }
 
+struct MHit { double dist, l2, l3; int tri; };
+
 // Closest hit of one mesh (object space).  Replaces Mesh::Intersect(ray, info) src/mesh.cpp:30-56 and the
 // recursive KD walk :58-92.
+// any-hit mode (shadow rays): ShadingHelper::GetShadowTransparency (src/shadinghelper.cpp:29-37) only asks whether
+// the node's closest hit satisfies Sqr(distance) < targetDistSq.  The closest hit satisfies it iff ANY accepted
+// candidate does (x -> Sqr(x / len) is monotone), so the walk stops at the first such candidate and never looks
+// beyond the light.
 template <bool STATS>
-QD_DEV bool mesh_intersect(const DScene& S, int mesh_idx, const DV& o, const DV& d, GHit& out, Counters& cnt) {
-    const qd_mesh m = S.meshes[mesh_idx];
+QD_DEV bool mesh_intersect(const DScene& S, int mesh_idx, const DV& o, const DV& d, bool any, double target, double rlen,
+                           MHit& out, Counters& cnt) {
+    const qd_mesh& m = S.meshes[mesh_idx];
     const DV md = -d;
     // slab interval of the ray in the mesh box, padded like BBox::IsInside's 1e-6 (src/bbox.cpp:24-31)
     double t0 = 0., t1 = kInf;
-    const double inv[3] = {1. / d.x, 1. / d.y, 1. / d.z};
+    const DV inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const double oa = comp(o, a), da = comp(d, a);
         const double lo = m.bbox_min[a] - 1e-6, hi = m.bbox_max[a] + 1e-6;
         if (da == 0.) { if (oa < lo || oa > hi) return false; continue; }
-        double ta = (lo - oa) * inv[a], tb = (hi - oa) * inv[a];
+        double ta = (lo - oa) * comp(inv, a), tb = (hi - oa) * comp(inv, a);
         if (ta > tb) { const double s = ta; ta = tb; tb = s; }
         t0 = fmax(t0, ta); t1 = fmin(t1, tb);
     }
+    if (any) t1 = fmin(t1, dsqrt(target) * rlen * (1. + 1e-9) + 1e-7);   // nothing beyond the light matters
     if (t0 > t1) return false;
 
+    const uint32_t flags = m.flags, tri_first = m.tri_first;
     double best = kInf, l2 = 0, l3 = 0;
     int tri = -1;
     if (m.kd_root < 0) {
-        for (uint32_t i = 0; i < m.tri_count; ++i)
-            if (tri_test<STATS>(S, m, i, o, d, md, best, l2, l3, cnt)) tri = (int)i;
+        const uint32_t n_tri = m.tri_count;
+        for (uint32_t i = 0; i < n_tri; ++i)
+            if (tri_test<STATS>(S, flags, tri_first, i, o, d, md, best, l2, l3, cnt)) {
+                tri = (int)i;
+                if (any && sqr(best / rlen) < target) break;
+            }
     } else {
         if (STATS) cnt.mesh_queries++;
         uint32_t stk_node[kKdStack];
@@ -127,14 +150,15 @@ QD_DEV bool mesh_intersect(const DScene& S, int mesh_idx, const DV& o, const DV&
         int sp = 0;
         uint32_t node = (uint32_t)m.kd_root;
         double tmin = t0, tmax = t1;
-        for (;;) {
-            qd_kdnode n = S.kd_nodes[node];
+        bool done = false;
+        while (!done) {
+            KdNode n = ld_kdnode(S, node);
             if (STATS) cnt.kd_nodes++;
             uint32_t axis = n.meta & 3u;
             while (axis != 3u) {
                 const uint32_t left = n.meta >> 2;
                 const double oa = comp(o, (int)axis);
-                const double t = (n.split - oa) * inv[axis];
+                const double t = (n.split - oa) * comp(inv, (int)axis);
                 // near child = the side the origin is on (src/mesh.cpp:75-77: right iff start > split); an origin
                 // exactly on the plane belongs to the side the ray travels into.  The sign of t is exact.
                 const bool right_first = oa > n.split || (oa == n.split && comp(d, (int)axis) > 0);
@@ -149,14 +173,17 @@ QD_DEV bool mesh_intersect(const DScene& S, int mesh_idx, const DV& o, const DV&
                     node = near_c;
                     tmax = (t == t) ? fmin(tmax, t + slack) : tmax;
                 }
-                n = S.kd_nodes[node];
+                n = ld_kdnode(S, node);
                 if (STATS) cnt.kd_nodes++;
                 axis = n.meta & 3u;
             }
             const uint32_t first = n.meta >> 2;
             for (uint32_t i = 0; i < n.count; ++i) {
                 const uint32_t local = S.leaf_tris[first + i];
-                if (tri_test<STATS>(S, m, local, o, d, md, best, l2, l3, cnt)) tri = (int)local;
+                if (tri_test<STATS>(S, flags, tri_first, local, o, d, md, best, l2, l3, cnt)) {
+                    tri = (int)local;
+                    if (any && sqr(best / rlen) < target) { done = true; break; }
+                }
             }
             // front-to-back: a hit inside this leaf's interval cannot be beaten by later leaves
             if (tri >= 0 && best <= tmax - (2e-7 + 2e-9 * fabs(tmax))) break;
@@ -168,15 +195,14 @@ QD_DEV bool mesh_intersect(const DScene& S, int mesh_idx, const DV& o, const DV&
         }
     }
     if (tri < 0) return false;
-    out.dist = best;
-    out.ip = o + d * best;
-    out.tri = tri; out.mesh = mesh_idx; out.l2 = l2; out.l3 = l3; out.dnd = 2;
+    out.dist = best; out.tri = tri; out.l2 = l2; out.l3 = l3;
     return true;
 }
 
 // Shading data of a mesh hit (src/mesh.cpp:141-163), evaluated once for the winner.
 QD_DEV void mesh_finish(const DScene& S, GHit& h, DV& dndx, DV& dndy, bool want_dnd) {
     const qd_mesh& m = S.meshes[h.mesh];
+    h.dnd = 2;
     const size_t t = (size_t)m.tri_first + (uint32_t)h.tri;
     const double* sh = S.tri_shade + t * 21;
     if (!(m.flags & QD_MESH_FACETED)) {
@@ -233,12 +259,11 @@ QD_DEV bool tri_fast(const DV& start, const DV& dir, const DV& A, const DV& B, c
 }
 
 // ---------------------------------------------------------------- heightfield (src/heightfield.cpp:20-100, :216-245)
-QD_DEV bool hf_intersect(const DScene& S, int hf, const DV& start, const DV& dir, GHit& out) {
+QD_DEV bool hf_intersect(const DScene& S, int hf, const DV& start, const DV& dir, double& out_dist) {
     const qd_heightfield& h = S.hfields[hf];
     const float* heights = S.hf_f32 + h.heights_off;
     const float* maxh = S.hf_f32 + h.maxheights_off;
     const float* highmap = S.hf_f32 + h.highmap_off;
-    const double* normals = S.hf_f64 + h.normals_off;
     const int W = (int)h.width, H = (int)h.height;
     auto get_height = [&](int x, int y) { x = min(max(x, 0), W - 1); y = min(max(y, 0), H - 1); return heights[(size_t)y * W + x]; };
     const DV step = dir / (dsqrt(sqr(dir.x) + sqr(dir.z)));
@@ -267,26 +292,34 @@ QD_DEV bool hf_intersect(const DScene& S, int hf, const DV& start, const DV& dir
             const DV C = mk(x0 + 1, get_height(x0 + 1, z0 + 1), z0 + 1);
             const DV D = mk(x0, get_height(x0, z0 + 1), z0 + 1);
             if (tri_fast(start, dir, A, B, D, closest) || tri_fast(start, dir, B, C, D, closest)) {
-                out.dist = closest;
-                out.ip = start + dir * closest;
-                // GetNormal: bilinear in float weights
-                const float fx = static_cast<float>(out.ip.x), fy = static_cast<float>(out.ip.z);
-                unsigned ux = (unsigned)floorf(fx), uy = (unsigned)floorf(fy);
-                const float pw = fx - ux, qw = fy - uy;
-                ux = min(ux, h.width - 1); uy = min(uy, h.height - 1);
-                const unsigned x1 = min(h.width - 1, ux + 1), y1 = min(h.height - 1, uy + 1);
-                auto nrm = [&](unsigned x, unsigned y) { return ld3(normals + ((size_t)y * W + x) * 3); };
-                out.n = nrm(ux, uy) * ((1 - pw) * (1 - qw)) + nrm(x1, uy) * ((pw) * (1 - qw)) +
-                        nrm(ux, y1) * ((1 - pw) * (qw)) + nrm(x1, y1) * ((pw) * (qw));
-                out.u = out.ip.x / h.width;
-                out.v = out.ip.z / h.height;
-                out.tri = -1; out.dnd = 1;
+                out_dist = closest;
                 return true;
             }
         }
         p = p_next;
     }
     return false;
+}
+
+// The rest of Heightfield::Intersect's outputs (src/heightfield.cpp:61-68) are functions of the hit distance.
+QD_DEV void hf_finish(const DScene& S, int hf, const DV& start, const DV& dir, double dist, GHit& out) {
+    const qd_heightfield& h = S.hfields[hf];
+    const double* normals = S.hf_f64 + h.normals_off;
+    const int W = (int)h.width;
+    out.dist = dist;
+    out.ip = start + dir * dist;
+    // GetNormal (:230-245): bilinear with float weights
+    const float fx = static_cast<float>(out.ip.x), fy = static_cast<float>(out.ip.z);
+    unsigned ux = (unsigned)floorf(fx), uy = (unsigned)floorf(fy);
+    const float pw = fx - ux, qw = fy - uy;
+    ux = min(ux, h.width - 1); uy = min(uy, h.height - 1);
+    const unsigned x1 = min(h.width - 1, ux + 1), y1 = min(h.height - 1, uy + 1);
+    auto nrm = [&](unsigned x, unsigned y) { return ld3(normals + ((size_t)y * W + x) * 3); };
+    out.n = nrm(ux, uy) * ((1 - pw) * (1 - qw)) + nrm(x1, uy) * ((pw) * (1 - qw)) +
+            nrm(ux, y1) * ((1 - pw) * (qw)) + nrm(x1, y1) * ((pw) * (qw));
+    out.u = out.ip.x / h.width;
+    out.v = out.ip.z / h.height;
+    out.tri = -1; out.dnd = 1;
 }
 
 // ---------------------------------------------------------------- analytic primitives (src/geometry.cpp)
@@ -398,54 +431,50 @@ QD_DEV bool leaf_inside(const qd_geom& g, const DV& p) {
     }
 }
 
-template <bool STATS>
-QD_DEV bool leaf_intersect(const DScene& S, const qd_geom& g, const DV& start, const DV& dir, GHit& out, Counters& cnt) {
+// Plane / Sphere / Cube / RegularPolygon
+QD_DEV bool prim_intersect(const qd_geom& g, const DV& start, const DV& dir, GHit& out) {
     switch (g.type) {
         case QD_GEOM_PLANE: return plane_intersect(g, start, dir, out);
         case QD_GEOM_SPHERE: return sphere_intersect(g, start, dir, out);
         case QD_GEOM_CUBE: return cube_intersect(g, start, dir, out);
         case QD_GEOM_REGPOLY: return regpoly_intersect(g, start, dir, out);
-        case QD_GEOM_MESH: return mesh_intersect<STATS>(S, g.a, start, dir, out, cnt);
-        case QD_GEOM_HEIGHTFIELD: return hf_intersect(S, g.a, start, dir, out);
         default: return false;
     }
 }
 
 QD_DEV bool csg_op(int op, bool a, bool b) { return op == QD_CSG_AND ? (a && b) : (op == QD_CSG_PLUS ? (a || b) : (a && !b)); }
 
-// CsgOp::Intersect, src/geometry.cpp:184-234.  Operands must be non-CSG geometries on the device
-// (qd_scene_create rejects nested CSG).
-template <bool STATS>
-QD_DEV bool csg_intersect(const DScene& S, const qd_geom& g, const DV& start, const DV& dir, GHit& out, Counters& cnt) {
+// CsgOp::Intersect, src/geometry.cpp:184-234.  On the device the operands must be analytic primitives
+// (qd_scene_create rejects CSG over CSG / meshes / heightfields; the oracle handles those).
+QD_DEV bool csg_intersect(const DScene& S, const qd_geom& g, const DV& start, const DV& dir, GHit& out) {
     const qd_geom ga = S.geoms[g.a], gb = S.geoms[g.b];
     GHit li, ri;
     bool inA = leaf_inside(ga, start), inB = leaf_inside(gb, start);
     const bool cur = csg_op(g.c, inA, inB);
-    bool lhit = leaf_intersect<STATS>(S, ga, start, dir, li, cnt);
-    bool rhit = leaf_intersect<STATS>(S, gb, start, dir, ri, cnt);
+    bool lhit = prim_intersect(ga, start, dir, li);
+    bool rhit = prim_intersect(gb, start, dir, ri);
     while (lhit || rhit) {
         if (lhit && (!rhit || li.dist <= ri.dist)) {
             inA = !inA;
             if (csg_op(g.c, inA, inB) != cur) { out = li; return true; }
             const double prev = li.dist;
-            lhit = leaf_intersect<STATS>(S, ga, li.ip + dir * 1e-6, dir, li, cnt);
+            lhit = prim_intersect(ga, li.ip + dir * 1e-6, dir, li);
             if (lhit) li.dist += prev + 1e-6;
         } else if (rhit && (!lhit || ri.dist <= li.dist)) {
             inB = !inB;
             if (csg_op(g.c, inA, inB) != cur) { out = ri; return true; }
             const double prev = ri.dist;
-            rhit = leaf_intersect<STATS>(S, gb, ri.ip + dir * 1e-6, dir, ri, cnt);
+            rhit = prim_intersect(gb, ri.ip + dir * 1e-6, dir, ri);
             if (rhit) ri.dist += prev + 1e-6;
         }
     }
     return false;
 }
 
-template <bool STATS>
-QD_DEV bool geom_intersect(const DScene& S, int gi, const DV& start, const DV& dir, GHit& out, Counters& cnt) {
-    const qd_geom g = S.geoms[gi];
-    if (g.type == QD_GEOM_CSG) return csg_intersect<STATS>(S, g, start, dir, out, cnt);
-    return leaf_intersect<STATS>(S, g, start, dir, out, cnt);
+// Analytic geometry (primitives and CSG of primitives): full hit record.
+QD_DEV bool analytic_intersect(const DScene& S, const qd_geom& g, const DV& start, const DV& dir, GHit& out) {
+    if (g.type == QD_GEOM_CSG) return csg_intersect(S, g, start, dir, out);
+    return prim_intersect(g, start, dir, out);
 }
 
 }  // namespace qd

@@ -91,41 +91,67 @@ struct LaneQueue {
 };
 
 // ------------------------------------------------------------------------------------------
-// Shadow query: product of shadowTransparency over all nodes whose closest hit is nearer than the
-// light (ShadingHelper::GetShadowTransparency, src/shadinghelper.cpp:20-40).  Once the product is
-// exactly 0 no later factor can change it, so the node loop stops there.
+// One ray task against the node list, one code path for both kinds of ray (so that lanes carrying
+// shadow rays and lanes carrying radiance rays run the same traversal instructions):
+//  * radiance ray: closest node in file order, strict '<' (src/main.cpp:23-38).  Only the winner's
+//    minimal record (node, distance, triangle, barycentrics) is carried through the search; its full
+//    hit record is rebuilt once at the end (analytic geometry is simply intersected again, which is
+//    deterministic; mesh / heightfield records are functions of the stored distance).
+//  * shadow ray: product of shadowTransparency over the nodes whose closest hit is nearer than the light
+//    (ShadingHelper::GetShadowTransparency, src/shadinghelper.cpp:20-40).  Once the product is exactly 0
+//    no later factor can change it, so the node loop stops there.
 template <bool STATS>
-QD_DEV float shadow_trace(const DScene& S, const DV& o, const DV& d, double target, Counters& cnt) {
-    float result = 1.f;
-    for (uint32_t i = 0; i < S.n_nodes; ++i) {
-        const qd_node& n = S.nodes[i];
-        const ObjRay r = to_object(n, o, d);
-        GHit h;
-        if (!geom_intersect<STATS>(S, n.geom, r.o, r.d, h, cnt)) continue;
-        const double dw = h.dist / r.len;
-        if (sqr(dw) < target) {
-            result *= n.shadow_transparency;
-            if (result == 0.f) break;
+QD_DEV int trace_nodes(const DScene& S, const DV& o, const DV& d, bool shadow, double target,
+                       float& transp, double& best_dw, GHit& hit, Counters& cnt) {
+    int best_node = -1;
+    best_dw = kInf; transp = 1.f;
+    double w_dist = 0, w_l2 = 0, w_l3 = 0;
+    int w_tri = -1;
+    const uint32_t n_nodes = S.n_nodes;
+    uint32_t i = 0;
+    bool final_pass = false;
+    for (;;) {
+        if (!final_pass && i == n_nodes) {
+            if (shadow || best_node < 0) break;
+            final_pass = true; i = (uint32_t)best_node;
         }
-    }
-    return result;
-}
-
-// Closest hit over all nodes in file order, strict '<' (src/main.cpp:23-38).
-template <bool STATS>
-QD_DEV int closest_hit(const DScene& S, const DV& o, const DV& d, GHit& best, double& best_dw, Counters& cnt) {
-    int node = -1;
-    best_dw = kInf;
-    for (uint32_t i = 0; i < S.n_nodes; ++i) {
         const qd_node& n = S.nodes[i];
         const ObjRay r = to_object(n, o, d);
-        GHit h;
-        if (!geom_intersect<STATS>(S, n.geom, r.o, r.d, h, cnt)) continue;
-        const double dw = h.dist / r.len;
-        if (best_dw <= dw) continue;
-        best_dw = dw; node = (int)i; best = h;
+        const qd_geom g = S.geoms[n.geom];
+        double dist = 0, c_l2 = 0, c_l3 = 0;
+        int c_tri = -1;
+        bool got;
+        if (g.type == QD_GEOM_MESH) {
+            if (final_pass) {
+                hit.dist = w_dist; hit.ip = r.o + r.d * w_dist; hit.tri = w_tri; hit.mesh = g.a; hit.l2 = w_l2; hit.l3 = w_l3;
+                break;
+            }
+            MHit mh;
+            got = mesh_intersect<STATS>(S, g.a, r.o, r.d, shadow, target, r.len, mh, cnt);
+            if (got) { dist = mh.dist; c_tri = mh.tri; c_l2 = mh.l2; c_l3 = mh.l3; }
+        } else if (g.type == QD_GEOM_HEIGHTFIELD) {
+            if (final_pass) { hf_finish(S, g.a, r.o, r.d, w_dist, hit); break; }
+            got = hf_intersect(S, g.a, r.o, r.d, dist);
+        } else {
+            GHit h;
+            got = analytic_intersect(S, g, r.o, r.d, h);
+            if (final_pass) { hit = h; break; }
+            dist = h.dist;
+        }
+        if (got) {
+            const double dw = dist / r.len;
+            if (shadow) {
+                if (sqr(dw) < target) {
+                    transp *= n.shadow_transparency;
+                    if (transp == 0.f) break;
+                }
+            } else if (!(best_dw <= dw)) {
+                best_dw = dw; best_node = (int)i; w_dist = dist; w_tri = c_tri; w_l2 = c_l2; w_l3 = c_l3;
+            }
+        }
+        ++i;
     }
-    return node;
+    return best_node;
 }
 
 // World-space IntersectionInfo of the winning hit (src/geometry.cpp:331-338).
@@ -270,101 +296,132 @@ QD_DEV uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+#ifndef QD_WAVES_PER_EU
+#define QD_WAVES_PER_EU 4
+#endif
+constexpr uint32_t kWavesPerCU = 4 * QD_WAVES_PER_EU;
+
+struct PixelSlot { int x, y; uint32_t out_idx; bool valid; };
+
+QD_DEV PixelSlot map_pixel(const Params& P, uint32_t unit, uint32_t p) {
+    PixelSlot s;
+    const int lx8 = p & 7, ly8 = p >> 3;
+    if (P.mode == 0) {
+        const int ux = unit % P.units_x, uy = unit / P.units_x;
+        const int px = ux * 8 + lx8, py = uy * 8 + ly8;
+        s.x = P.x0 + px; s.y = P.y0 + py;
+        s.valid = px < P.rw && py < P.rh;
+        s.out_idx = (uint32_t)py * (uint32_t)P.rw + (uint32_t)px;
+    } else {
+        const int sub_per_side = P.tile / 8, spt = sub_per_side * sub_per_side;
+        const int k = unit / spt, sb = unit % spt;
+        const int t = P.phase + k * P.stride;
+        const int tx = t % P.tiles_x, ty = t / P.tiles_x;
+        const int lx = (sb % sub_per_side) * 8 + lx8, ly = (sb / sub_per_side) * 8 + ly8;
+        s.x = tx * P.tile + lx; s.y = ty * P.tile + ly;
+        s.valid = s.x < P.W && s.y < P.H;
+        s.out_idx = (uint32_t)k * (uint32_t)(P.tile * P.tile) + (uint32_t)(ly * P.tile + lx);
+    }
+    return s;
+}
+
+// Persistent lanes: a lane that finishes its pixel immediately takes the next pixel of the wave's
+// current 8x8 unit (or of a freshly fetched unit), so no lane waits for the slowest pixel of a tile.
 template <bool STATS>
-__global__ __launch_bounds__(64) void trace_kernel(const DScene S, const Params P) {
+__global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene S, const Params P) {
     const uint32_t lane = threadIdx.x;
     const size_t gl = (size_t)blockIdx.x * 64 + lane;
     LaneQueue q;
     q.base = P.stack + gl; q.stride = P.n_lanes; q.cap = P.stack_cap; q.sp = 0; q.err = P.error_flag;
     Counters cnt; cnt.kd_nodes = cnt.tris = cnt.mesh_queries = 0;
     uint32_t n_rays = 0, n_primary = 0, n_shadow = 0, n_killed = 0;
-    const DV TL = ld3(P.cam.top_left), TR = ld3(P.cam.top_right), BL = ld3(P.cam.bottom_left), pos = ld3(P.cam.position);
+
+    uint32_t unit = 0, unit_next = 64;     // wave-uniform: current unit and its first unassigned pixel
+    bool pool_empty = false;
+    bool have_px = false;
+    uint32_t out_idx = 0;
+    Col acc = mkc(0, 0, 0);
 
     for (;;) {
-        uint32_t unit = 0;
-        if (lane == 0) unit = fetch_unit(P, blockIdx.x & 7u);
-        unit = __shfl(unit, 0, 64);
-        if (unit == 0xffffffffu) break;
-
-        // unit -> pixel
-        int x, y; size_t out_idx; bool valid;
-        const int lx8 = lane & 7, ly8 = lane >> 3;
-        if (P.mode == 0) {
-            const int ux = unit % P.units_x, uy = unit / P.units_x;
-            const int px = ux * 8 + lx8, py = uy * 8 + ly8;
-            x = P.x0 + px; y = P.y0 + py;
-            valid = px < P.rw && py < P.rh;
-            out_idx = (size_t)py * P.rw + px;
-        } else {
-            const int sub_per_side = P.tile / 8, spt = sub_per_side * sub_per_side;
-            const int k = unit / spt, sb = unit % spt;
-            const int t = P.phase + k * P.stride;
-            const int tx = t % P.tiles_x, ty = t / P.tiles_x;
-            const int lx = (sb % sub_per_side) * 8 + lx8, ly = (sb / sub_per_side) * 8 + ly8;
-            x = tx * P.tile + lx; y = ty * P.tile + ly;
-            valid = x < P.W && y < P.H;
-            out_idx = (size_t)k * P.tile * P.tile + (size_t)ly * P.tile + lx;
-        }
-
-        Col acc = mkc(0, 0, 0);
-        if (valid) {
-            // Camera::GetScreenRay, src/camera.cpp:26-41 (integer pixel coordinates, no +0.5)
-            const DV through = TL + (TR - TL) * ((double)x / P.W) + (BL - TL) * ((double)y / P.H);
-            Task t;
-            t.o = pos; t.d = normalize(through - pos);
-            t.w = mkc(1.f, 1.f, 1.f);
-            t.flags_depth = kFlagPrimary;
-            t.path = pixel_path(x, y, 0);
-            t.aux0 = t.aux1 = 0;
-            q.push(t);
-            ++n_primary;
-        }
-
-        while (q.sp > 0) {
-            const Task t = q.pop();
-            if (t.flags_depth & kFlagShadow) {
-                ++n_shadow;
-                const float st = shadow_trace<STATS>(S, t.o, t.d, t.aux0, cnt);
-                acc = acc + t.w * (float)((double)st * t.aux1);
-                continue;
-            }
-            const uint32_t depth = t.flags_depth & kDepthMask;
-            if (depth > P.max_depth) { ++n_killed; continue; }          // src/main.cpp:20-21
-            ++n_rays;
-            GHit h; double dw;
-            const int node = closest_hit<STATS>(S, t.o, t.d, h, dw, cnt);
-            if ((t.flags_depth & kFlagPrimary) && P.hit_node) {
-                P.hit_node[out_idx] = node;
-                P.hit_tri[out_idx] = node >= 0 ? h.tri : -1;
-                P.hit_dist[out_idx] = node >= 0 ? dw : 0.;
-            }
-            if (node < 0) {
-                if (S.env_present) acc = acc + t.w * env_lookup(S, t.d);
-                continue;
-            }
-            const qd_node& n = S.nodes[node];
-            Info info;
-            assemble_info(S, n, h, dw, t.d, info);
-            if (n.bump_tex >= 0) tex_modify_normal(S, n.bump_tex, info);
-            const qd_shader top = S.shaders[n.shader];
-            if (top.type == QD_SH_LAYERED) {
-                // Layered::Shade (src/shading.cpp:260-275): result = b*layer + (1-b)*result, i.e. layer i carries
-                // b_i * prod_{j>i}(1-b_j); walk the layers from the last to the first keeping that suffix product.
-                Col suffix = mkc(1.f, 1.f, 1.f);
-                for (int i = top.i1 - 1; i >= 0; --i) {
-                    const qd_layer l = S.layers[top.i0 + i];
-                    Col blend = ldc(l.blend);
-                    if (l.tex >= 0) blend = blend * tex_sample(S, l.tex, info);
-                    eval_leaf_shader(S, P, l.shader, t.w * (blend * suffix), (uint32_t)i + 1, t, depth, info, acc, q);
-                    suffix = suffix * (mkc(1.f, 1.f, 1.f) - blend);
-                }
-            } else {
-                eval_leaf_shader(S, P, n.shader, t.w, 0, t, depth, info, acc, q);
-            }
-        }
-        if (valid) {
-            float* o = (P.mode == 0) ? P.rgb + (size_t)(y - P.y0) * P.pitch + (size_t)(x - P.x0) * 3 : P.rgb + out_idx * 3;
+        if (have_px && q.sp == 0) {        // pixel finished: write it (vfb[y][x] = Raytrace(...), src/main.cpp:96)
+            float* o = P.rgb + (P.mode == 0 ? (size_t)(out_idx / (uint32_t)P.rw) * P.pitch + (size_t)(out_idx % (uint32_t)P.rw) * 3
+                                            : (size_t)out_idx * 3);
             o[0] = acc.r; o[1] = acc.g; o[2] = acc.b;
+            have_px = false;
+        }
+        unsigned long long idle = __ballot(!have_px);
+        while (idle != 0ull && !pool_empty) {
+            if (unit_next >= 64u) {
+                uint32_t u = 0;
+                if (lane == 0) u = fetch_unit(P, blockIdx.x & 7u);
+                u = __shfl(u, 0, 64);
+                if (u == 0xffffffffu) { pool_empty = true; break; }
+                unit = u; unit_next = 0;
+            }
+            const uint32_t avail = 64u - unit_next;
+            const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+            if (!have_px && rank < avail) {
+                const PixelSlot px = map_pixel(P, unit, unit_next + rank);
+                if (px.valid) {
+                    // Camera::GetScreenRay, src/camera.cpp:26-41 (integer pixel coordinates, no +0.5)
+                    const DV TL = ld3(P.cam.top_left), TR = ld3(P.cam.top_right), BL = ld3(P.cam.bottom_left), pos = ld3(P.cam.position);
+                    const DV through = TL + (TR - TL) * ((double)px.x / P.W) + (BL - TL) * ((double)px.y / P.H);
+                    Task t;
+                    t.o = pos; t.d = normalize(through - pos);
+                    t.w = mkc(1.f, 1.f, 1.f);
+                    t.flags_depth = kFlagPrimary;
+                    t.path = pixel_path(px.x, px.y, 0);
+                    t.aux0 = t.aux1 = 0;
+                    q.push(t);
+                    ++n_primary;
+                    have_px = true; out_idx = px.out_idx; acc = mkc(0, 0, 0);
+                }
+            }
+            const uint32_t n_idle = __popcll(idle);
+            unit_next += n_idle < avail ? n_idle : avail;
+            idle = __ballot(!have_px);
+        }
+        if (__ballot(have_px) == 0ull) break;      // pool empty and nothing in flight in this wave
+        if (!have_px) continue;
+
+        const Task t = q.pop();
+        const bool shadow = (t.flags_depth & kFlagShadow) != 0;
+        const uint32_t depth = t.flags_depth & kDepthMask;
+        if (!shadow && depth > P.max_depth) { ++n_killed; continue; }          // src/main.cpp:20-21
+        if (shadow) ++n_shadow; else ++n_rays;
+        GHit h; double dw; float transp;
+        const int node = trace_nodes<STATS>(S, t.o, t.d, shadow, t.aux0, transp, dw, h, cnt);
+        if (shadow) {
+            acc = acc + t.w * (float)((double)transp * t.aux1);
+            continue;
+        }
+        if ((t.flags_depth & kFlagPrimary) && P.hit_node) {
+            P.hit_node[out_idx] = node;
+            P.hit_tri[out_idx] = node >= 0 ? h.tri : -1;
+            P.hit_dist[out_idx] = node >= 0 ? dw : 0.;
+        }
+        if (node < 0) {
+            if (S.env_present) acc = acc + t.w * env_lookup(S, t.d);
+            continue;
+        }
+        const qd_node& n = S.nodes[node];
+        Info info;
+        assemble_info(S, n, h, dw, t.d, info);
+        if (n.bump_tex >= 0) tex_modify_normal(S, n.bump_tex, info);
+        const qd_shader top = S.shaders[n.shader];
+        if (top.type == QD_SH_LAYERED) {
+            // Layered::Shade (src/shading.cpp:260-275): result = b*layer + (1-b)*result, i.e. layer i carries
+            // b_i * prod_{j>i}(1-b_j); walk the layers from the last to the first keeping that suffix product.
+            Col suffix = mkc(1.f, 1.f, 1.f);
+            for (int i = top.i1 - 1; i >= 0; --i) {
+                const qd_layer l = S.layers[top.i0 + i];
+                Col blend = ldc(l.blend);
+                if (l.tex >= 0) blend = blend * tex_sample(S, l.tex, info);
+                eval_leaf_shader(S, P, l.shader, t.w * (blend * suffix), (uint32_t)i + 1, t, depth, info, acc, q);
+                suffix = suffix * (mkc(1.f, 1.f, 1.f) - blend);
+            }
+        } else {
+            eval_leaf_shader(S, P, n.shader, t.w, 0, t, depth, info, acc, q);
         }
     }
 
@@ -450,7 +507,7 @@ int ensure_stack(qd_scene* s, uint32_t max_depth) {
     if (cap64 > 4096) return set_err("ray queue bound too large for this scene (samples x depth)");
     const uint32_t cap = (uint32_t)cap64;
     if (s->stack && cap <= s->stack_cap) return 0;
-    if (s->stack) { hipFree(s->stack); s->stack = nullptr; }
+    if (s->stack) { (void)hipFree(s->stack); s->stack = nullptr; }
     HIP_TRY(hipMalloc((void**)&s->stack, (size_t)cap * kEntryWords * 8 * s->n_lanes));
     s->stack_cap = cap;
     return 0;
@@ -506,8 +563,11 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
         const qd_geom& g = desc->geoms[i];
         if (g.type == QD_GEOM_CSG) {
             if (g.a < 0 || g.b < 0 || (uint32_t)g.a >= desc->n_geoms || (uint32_t)g.b >= desc->n_geoms) return set_err("qd_scene_create: CSG operand out of range");
-            if (desc->geoms[g.a].type == QD_GEOM_CSG || desc->geoms[g.b].type == QD_GEOM_CSG)
-                return set_err("qd_scene_create: nested CSG operands are not supported by the device path");
+            for (int op : {g.a, g.b}) {
+                const int ot = desc->geoms[op].type;
+                if (ot == QD_GEOM_CSG || ot == QD_GEOM_MESH || ot == QD_GEOM_HEIGHTFIELD)
+                    return set_err("qd_scene_create: CSG operands must be analytic primitives on the device path (no nested CSG, mesh or heightfield operands)");
+            }
         } else if (g.type == QD_GEOM_MESH) {
             if (g.a < 0 || (uint32_t)g.a >= desc->n_meshes) return set_err("qd_scene_create: mesh index out of range");
         } else if (g.type == QD_GEOM_HEIGHTFIELD) {
@@ -607,7 +667,7 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     d.env_present = desc->env_present; d.env_bilinear = desc->env_bilinear;
     for (int f = 0; f < 6; ++f) d.env_faces[f] = desc->env_faces[f];
     s->spawn0 = spawn0; s->spawn1 = spawn1;
-    s->n_lanes = (uint32_t)(g_num_cu > 0 ? g_num_cu : 256) * 8u * 64u;
+    s->n_lanes = (uint32_t)(g_num_cu > 0 ? g_num_cu : 256) * kWavesPerCU * 64u;
     if (!rc && hipMalloc((void**)&s->queue_ctr, 8 * sizeof(uint32_t)) != hipSuccess) rc = set_err("hipMalloc(queue counters) failed");
     if (!rc && hipMalloc((void**)&s->stats, 8 * sizeof(unsigned long long)) != hipSuccess) rc = set_err("hipMalloc(stats) failed");
     if (!rc && hipMalloc((void**)&s->error_flag, sizeof(int)) != hipSuccess) rc = set_err("hipMalloc(error flag) failed");
@@ -620,11 +680,11 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
 
 extern "C" void qd_scene_destroy(qd_scene* s) {
     if (!s) return;
-    for (void* p : s->allocs) hipFree(p);
-    if (s->stack) hipFree(s->stack);
-    if (s->queue_ctr) hipFree(s->queue_ctr);
-    if (s->stats) hipFree(s->stats);
-    if (s->error_flag) hipFree(s->error_flag);
+    for (void* p : s->allocs) (void)hipFree(p);
+    if (s->stack) (void)hipFree(s->stack);
+    if (s->queue_ctr) (void)hipFree(s->queue_ctr);
+    if (s->stats) (void)hipFree(s->stats);
+    if (s->error_flag) (void)hipFree(s->error_flag);
     delete s;
 }
 
@@ -645,8 +705,8 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = 0;
     auto cleanup = [&]() {
-        if (d_rgb) hipFree(d_rgb); if (d_hn) hipFree(d_hn); if (d_ht) hipFree(d_ht); if (d_hd) hipFree(d_hd);
-        if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1);
+        if (d_rgb) (void)hipFree(d_rgb); if (d_hn) (void)hipFree(d_hn); if (d_ht) (void)hipFree(d_ht); if (d_hd) (void)hipFree(d_hd);
+        if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
     };
 #define TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return -1; } } while (0)
     TRY2(hipMalloc((void**)&d_rgb, npx * 3 * sizeof(float)));
@@ -728,6 +788,6 @@ extern "C" int qd_scene_check(qd_scene* s) {
     if (!s) return set_err("qd_scene_check: null scene");
     int f = 0;
     HIP_TRY(hipMemcpy(&f, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (f) { hipMemset(s->error_flag, 0, sizeof(int)); return set_err("ray queue overflow on device"); }
+    if (f) { (void)hipMemset(s->error_flag, 0, sizeof(int)); return set_err("ray queue overflow on device"); }
     return 0;
 }

@@ -18,7 +18,7 @@ class DeviceError(RuntimeError):
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "lib", "libqdtrace.so")
+        path = os.environ.get("QDTRACE_LIB") or os.path.join(_HERE, "lib", "libqdtrace.so")   # override: A/B builds of the same kernels
         if not os.path.exists(path):
             raise DeviceError(f"{path} is missing: the HIP extension was not built (python -m raytracing_amd.build device)")
         L = C.CDLL(path)
