@@ -32,7 +32,8 @@ struct DScene {
     const double* tri_gnormal;
     const double* tri_shade;
     const qd_kdnode* kd_nodes;
-    const uint32_t* leaf_tris;
+    const uint32_t* leaf_tris;    // device copy holds GLOBAL triangle indices (mesh tri_first added)
+    const double* leaf_verts;     // 9 doubles per leaf reference, in leaf order: a leaf's triangles are contiguous
     const float* texels;
     const float* hf_f32;
     const double* hf_f64;
@@ -69,12 +70,13 @@ QD_DEV KdNode ld_kdnode(const DScene& S, uint32_t i) {
 // Mesh::Intersect(ray, triangle, info), src/mesh.cpp:111-168.  Returns true when the triangle
 // replaces the running hit.  The three quotients are only formed once the sign tests (which are
 // exact consequences of `gamma < 0`, `lambda2 < 0`, `lambda3 < 0`) have passed.
-template <bool STATS>
-QD_DEV bool tri_test(const DScene& S, uint32_t flags, uint32_t tri_first, uint32_t local, const DV& o, const DV& d, const DV& md,
+struct TriV { DV A, AB, AC; };
+QD_DEV TriV ld_tri(const double* tv) { TriV t; t.A = ld3(tv); t.AB = ld3(tv + 3); t.AC = ld3(tv + 6); return t; }
+
+template <bool STATS, class GetGlobal>
+QD_DEV bool tri_test(const DScene& S, uint32_t flags, const TriV& tr, GetGlobal global_index, const DV& o, const DV& d, const DV& md,
                      double& best, double& l2o, double& l3o, Counters& cnt) {
-    const size_t t = (size_t)tri_first + local;
-    const double* tv = S.tri_verts + t * 9;
-    const DV A = ld3(tv), AB = ld3(tv + 3), AC = ld3(tv + 6);
+    const DV A = tr.A, AB = tr.AB, AC = tr.AC;
     const DV N = cross(AB, AC);
     const double dcr = dot(N, md);                 // Det(AB, AC, -D)
     if (flags & QD_MESH_BACKCULL) {
@@ -84,7 +86,7 @@ QD_DEV bool tri_test(const DScene& S, uint32_t flags, uint32_t tri_first, uint32
         const double mag = fabs(N.x * d.x) + fabs(N.y * d.y) + fabs(N.z * d.z);
         bool cull;
         if (fabs(dcr) > 1e-12 * mag) cull = dcr < 0;
-        else cull = dot(d, ld3(S.tri_gnormal + t * 3)) > 0;
+        else cull = dot(d, ld3(S.tri_gnormal + (size_t)global_index() * 3)) > 0;
         if (cull) return false;
     }
     if (STATS) cnt.tris++;
@@ -138,11 +140,13 @@ QD_DEV bool mesh_intersect(const DScene& S, int mesh_idx, const DV& o, const DV&
     int tri = -1;
     if (m.kd_root < 0) {
         const uint32_t n_tri = m.tri_count;
-        for (uint32_t i = 0; i < n_tri; ++i)
-            if (tri_test<STATS>(S, flags, tri_first, i, o, d, md, best, l2, l3, cnt)) {
+        for (uint32_t i = 0; i < n_tri; ++i) {
+            const TriV tr = ld_tri(S.tri_verts + (size_t)(tri_first + i) * 9);
+            if (tri_test<STATS>(S, flags, tr, [&]() { return tri_first + i; }, o, d, md, best, l2, l3, cnt)) {
                 tri = (int)i;
                 if (any && sqr(best / rlen) < target) break;
             }
+        }
     } else {
         if (STATS) cnt.mesh_queries++;
         uint32_t stk_node[kKdStack];
@@ -177,12 +181,19 @@ QD_DEV bool mesh_intersect(const DScene& S, int mesh_idx, const DV& o, const DV&
                 if (STATS) cnt.kd_nodes++;
                 axis = n.meta & 3u;
             }
-            const uint32_t first = n.meta >> 2;
-            for (uint32_t i = 0; i < n.count; ++i) {
-                const uint32_t local = S.leaf_tris[first + i];
-                if (tri_test<STATS>(S, flags, tri_first, local, o, d, md, best, l2, l3, cnt)) {
-                    tri = (int)local;
-                    if (any && sqr(best / rlen) < target) { done = true; break; }
+            const uint32_t first = n.meta >> 2, count = n.count;
+            if (count) {
+                // the leaf's triangles are contiguous in leaf_verts: fetch triangle i+1 while testing triangle i
+                const double* tv = S.leaf_verts + (size_t)first * 9;
+                TriV cur = ld_tri(tv);
+                for (uint32_t i = 0; i < count; ++i) {
+                    TriV nxt = cur;
+                    if (i + 1 < count) nxt = ld_tri(tv + (size_t)(i + 1) * 9);
+                    if (tri_test<STATS>(S, flags, cur, [&]() { return S.leaf_tris[first + i]; }, o, d, md, best, l2, l3, cnt)) {
+                        tri = (int)(S.leaf_tris[first + i] - tri_first);
+                        if (any && sqr(best / rlen) < target) { done = true; break; }
+                    }
+                    cur = nxt;
                 }
             }
             // front-to-back: a hit inside this leaf's interval cannot be beaten by later leaves

@@ -443,6 +443,15 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
     }
 }
 
+// leaf_verts[ref] = tri_verts[leaf_tris[ref]] (9 doubles each): one pass at scene creation
+__global__ void gather_leaf_verts_kernel(const double* __restrict__ tri_verts, const uint32_t* __restrict__ leaf_tris,
+                                         double* __restrict__ leaf_verts, size_t n_words) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_words) return;
+    const size_t ref = i / 9, w = i % 9;
+    leaf_verts[i] = tri_verts[(size_t)leaf_tris[ref] * 9 + w];
+}
+
 __global__ void untile_kernel(const float* __restrict__ src, float* __restrict__ dst, int W, int H, int tile, int stride, int tpr) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W || y >= H) return;
@@ -488,6 +497,53 @@ struct qd_scene {
 };
 
 namespace {
+
+// KD nodes re-ordered for the device: a node's two children and their four children share one 128-byte
+// block (8 slots of 16 bytes, 6 used), so a root-to-leaf walk touches a new cache line every second level.
+// Node contents and child adjacency (index, index + 1) are unchanged -- only positions move -- so the
+// traversal code is oblivious to the layout.  Leaf references become global triangle indices.
+void relayout_kd(const qd_scene_desc* d, std::vector<qd_kdnode>& out, std::vector<qd_mesh>& meshes, std::vector<uint32_t>& leaf_global) {
+    const qd_kdnode* src = d->kd_nodes;
+    leaf_global.assign(d->leaf_tris, d->leaf_tris + d->n_leaf_tris);
+    const qd_kdnode empty{0., 3u, 0u};   // unused slot = empty leaf
+    struct Item { uint32_t src_pair; size_t dst_parent; };
+    std::vector<Item> stack;
+    for (qd_mesh& m : meshes) {
+        if (m.kd_root < 0) continue;
+        auto mark_leaf = [&](const qd_kdnode& n) {
+            const size_t first = n.meta >> 2;
+            for (size_t r = first; r < first + n.count; ++r) leaf_global[r] = d->leaf_tris[r] + m.tri_first;
+        };
+        const size_t rb = out.size();
+        out.resize(rb + 8, empty);
+        out[rb] = src[m.kd_root];
+        m.kd_root = (int32_t)rb;
+        if ((out[rb].meta & 3u) == 3u) { mark_leaf(out[rb]); continue; }
+        stack.push_back(Item{out[rb].meta >> 2, rb});
+        while (!stack.empty()) {
+            const Item it = stack.back(); stack.pop_back();
+            const size_t base = out.size();
+            out.resize(base + 8, empty);
+            out[it.dst_parent].meta = ((uint32_t)base << 2) | (out[it.dst_parent].meta & 3u);
+            Item pending[4]; int np = 0;
+            for (int k = 0; k < 2; ++k) {
+                const qd_kdnode n = src[it.src_pair + k];
+                out[base + k] = n;
+                if ((n.meta & 3u) == 3u) { mark_leaf(n); continue; }
+                const uint32_t gc = n.meta >> 2;
+                const size_t gslot = base + 2 + 2 * k;
+                out[base + k].meta = ((uint32_t)gslot << 2) | (n.meta & 3u);
+                for (int j = 0; j < 2; ++j) {
+                    const qd_kdnode g = src[gc + j];
+                    out[gslot + j] = g;
+                    if ((g.meta & 3u) == 3u) mark_leaf(g);
+                    else pending[np++] = Item{g.meta >> 2, gslot + (size_t)j};
+                }
+            }
+            for (int q = np - 1; q >= 0; --q) stack.push_back(pending[q]);   // depth-first, left subtree next
+        }
+    }
+}
 
 template <class T>
 int upload(qd_scene* s, const T* src, size_t n, const T** dst) {
@@ -647,7 +703,12 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     int rc = 0;
     rc |= upload(s, desc->nodes, desc->n_nodes, &d.nodes);
     rc |= upload(s, desc->geoms, desc->n_geoms, &d.geoms);
-    rc |= upload(s, desc->meshes, desc->n_meshes, &d.meshes);
+    std::vector<qd_kdnode> kd_blocked;
+    std::vector<qd_mesh> meshes_dev(desc->meshes, desc->meshes + desc->n_meshes);
+    std::vector<uint32_t> leaf_global;
+    relayout_kd(desc, kd_blocked, meshes_dev, leaf_global);
+    if (kd_blocked.size() >= (1u << 30)) { delete s; return set_err("qd_scene_create: KD tree too large for 30-bit node indices"); }
+    rc |= upload(s, meshes_dev.data(), meshes_dev.size(), &d.meshes);
     rc |= upload(s, desc->hfields, desc->n_hfields, &d.hfields);
     rc |= upload(s, desc->shaders, desc->n_shaders, &d.shaders);
     rc |= upload(s, desc->layers, desc->n_layers, &d.layers);
@@ -658,8 +719,22 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     rc |= upload(s, desc->tri_verts, (size_t)desc->n_tris * 9, &d.tri_verts);
     rc |= upload(s, desc->tri_gnormal, (size_t)desc->n_tris * 3, &d.tri_gnormal);
     rc |= upload(s, desc->tri_shade, (size_t)desc->n_tris * 21, &d.tri_shade);
-    rc |= upload(s, desc->kd_nodes, (size_t)desc->n_kd_nodes, &d.kd_nodes);
-    rc |= upload(s, desc->leaf_tris, (size_t)desc->n_leaf_tris, &d.leaf_tris);
+    rc |= upload(s, kd_blocked.data(), kd_blocked.size(), &d.kd_nodes);
+    rc |= upload(s, leaf_global.data(), leaf_global.size(), &d.leaf_tris);
+    if (!rc) {
+        const size_t n_words = leaf_global.size() * 9;
+        void* lv = nullptr;
+        if (hipMalloc(&lv, (n_words ? n_words : 1) * sizeof(double) + 256) != hipSuccess) rc = set_err("hipMalloc(leaf_verts) failed");
+        else {
+            s->allocs.push_back(lv);
+            d.leaf_verts = (const double*)lv;
+            if (n_words) {
+                hipLaunchKernelGGL(gather_leaf_verts_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, nullptr,
+                                   d.tri_verts, d.leaf_tris, (double*)lv, n_words);
+                if (hipDeviceSynchronize() != hipSuccess) rc = set_err("gather_leaf_verts failed");
+            }
+        }
+    }
     rc |= upload(s, desc->texels, (size_t)desc->n_texels * 3, &d.texels);
     rc |= upload(s, desc->hf_f32, (size_t)desc->n_hf_f32, &d.hf_f32);
     rc |= upload(s, desc->hf_f64, (size_t)desc->n_hf_f64, &d.hf_f64);
