@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kd-refine", default=None, help="'max_leaf,step_cost' for qd_set_kd_refine (tuning; default = library default)")
     args = ap.parse_args()
     args.width_set = args.width is not None
     args.width = args.width or 3840
@@ -96,6 +97,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
+    if args.kd_refine:
+        ml, sc = args.kd_refine.split(",")
+        device.set_kd_refine(int(ml), float(sc))
     scene, workload = build_scene(args)
     fr = renderer.FrameRenderer(scene, tile=args.tile, rank=rank, world=world, local_device=local)
     W, H = fr.W, fr.H

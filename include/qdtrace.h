@@ -273,6 +273,19 @@ int qd_quantize_bgr8_async(const float* rgb_dev, uint8_t* bgr_dev, int width, in
  * nbIntersections, src/mesh.cpp:20-22); off by default because the counters cost registers. */
 int qd_set_counting(int on);
 
+/* Replaces: the leaf criterion of Mesh::BuildKD (src/mesh.cpp:218, TRIANGLES_PER_LEAF = 20 in
+ * src/constants.h:14) for the DEVICE copy of the tree only.  qd_scene_create keeps the caller's
+ * tree and splits each of its leaves further with a surface-area heuristic until a leaf holds at most
+ * `max_leaf_tris` triangles or a split costs more than it saves (`step_cost` = cost of one descent
+ * step in triangle tests).  max_leaf_tris = 0 uses the caller's tree unchanged.  Default (2, 0.6).
+ * The closest hit does not depend on the grouping; only exact distance ties between two different
+ * triangles may resolve differently.  Applies to scenes created after the call. */
+int qd_set_kd_refine(int max_leaf_tris, double step_cost);
+
+/* Size of the device tree of a scene (after refinement): nodes, leaf references, leaves, largest leaf.
+ * Any pointer may be NULL.  The reference prints the same figures for its own tree at src/mesh.cpp:211-213. */
+int qd_scene_kd_info(const qd_scene* scene, uint64_t* nodes, uint64_t* leaf_refs, uint64_t* leaves, uint64_t* max_leaf);
+
 /* Replaces: nothing in the reference (its render loop cannot fail).  Returns <0 if an asynchronous
  * launch on this scene overflowed its ray queue since the last check (synchronises the device). */
 int qd_scene_check(qd_scene* scene);

@@ -52,7 +52,15 @@ struct GHit {
     int dnd;            // 0: dNdx/dNdy left at zero (sphere, cube, polygon), 1: (1,0,0)/(0,0,1), 2: from the mesh triangle
 };
 
-struct Counters { uint32_t kd_nodes, tris, mesh_queries; };
+struct Counters {
+    uint32_t kd_nodes, tris, mesh_queries;
+    unsigned long long t_desc, t_leaf, t_a, t_b, t_c, t_d;   // diagnostic build only (QD_PROFILE): wave cycles per region
+};
+#ifdef QD_PROFILE
+#define QD_STAMP() __builtin_amdgcn_s_memtime()
+#else
+#define QD_STAMP() 0ull
+#endif
 
 constexpr int kKdStack = 72;
 
@@ -67,15 +75,50 @@ QD_DEV KdNode ld_kdnode(const DScene& S, uint32_t i) {
 }   // MAX_TREE_DEPTH 64 -> leaves at depth <= 65 (src/constants.h:13, src/mesh.cpp:218)
 
 // ---------------------------------------------------------------- mesh: triangle test
+// The mesh query is compiled as a real function (not inlined into the kernel): the traversal loop then gets
+// a register allocation of its own and the kernel's long-lived state is saved once around the call instead of
+// being spilled and reloaded inside the loop.  Pointers cross the call as global-address-space pointers so the
+// loop uses global_load, not flat_load.
+#define QD_GLOBAL __attribute__((address_space(1)))
+typedef const QD_GLOBAL double* gp_f64;
+typedef const QD_GLOBAL uint32_t* gp_u32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const QD_GLOBAL u32x4* gp_u32x4;
+
+struct MeshData {            // the arrays a mesh query reads, by value
+    const qd_mesh* meshes;
+    const qd_kdnode* kd_nodes;
+    const double* leaf_verts;
+    const uint32_t* leaf_tris;
+    const double* tri_verts;
+    const double* tri_gnormal;
+};
+QD_DEV MeshData mesh_data(const DScene& S) { return MeshData{S.meshes, S.kd_nodes, S.leaf_verts, S.leaf_tris, S.tri_verts, S.tri_gnormal}; }
+
+QD_DEV KdNode kd_unpack(const u32x4 v) {
+    KdNode n;
+    n.split = __hiloint2double((int)v.y, (int)v.x);
+    n.meta = v.z; n.count = v.w;
+    return n;
+}
+
+// component pick without control flow (the ternary on doubles compiles to branches inside the traversal loop)
+QD_DEV double pick(const DV& a, uint32_t axis) {
+    const bool is0 = axis == 0u, is1 = axis == 1u;
+    const int lo = is0 ? __double2loint(a.x) : (is1 ? __double2loint(a.y) : __double2loint(a.z));
+    const int hi = is0 ? __double2hiint(a.x) : (is1 ? __double2hiint(a.y) : __double2hiint(a.z));
+    return __hiloint2double(hi, lo);
+}
+
 // Mesh::Intersect(ray, triangle, info), src/mesh.cpp:111-168.  Returns true when the triangle
 // replaces the running hit.  The three quotients are only formed once the sign tests (which are
 // exact consequences of `gamma < 0`, `lambda2 < 0`, `lambda3 < 0`) have passed.
 struct TriV { DV A, AB, AC; };
-QD_DEV TriV ld_tri(const double* tv) { TriV t; t.A = ld3(tv); t.AB = ld3(tv + 3); t.AC = ld3(tv + 6); return t; }
+template <class P> QD_DEV TriV ld_tri(P tv) { TriV t; t.A = ld3(tv); t.AB = ld3(tv + 3); t.AC = ld3(tv + 6); return t; }
 
 template <bool STATS, class GetGlobal>
-QD_DEV bool tri_test(const DScene& S, uint32_t flags, const TriV& tr, GetGlobal global_index, const DV& o, const DV& d, const DV& md,
-                     double& best, double& l2o, double& l3o, Counters& cnt) {
+QD_DEV bool tri_test(gp_f64 gnormal, uint32_t flags, const TriV& tr, GetGlobal global_index, const DV& o, const DV& d, const DV& md,
+                     double& best, double& l2o, double& l3o, uint32_t& n_tests) {
     const DV A = tr.A, AB = tr.AB, AC = tr.AC;
     const DV N = cross(AB, AC);
     const double dcr = dot(N, md);                 // Det(AB, AC, -D)
@@ -86,10 +129,10 @@ QD_DEV bool tri_test(const DScene& S, uint32_t flags, const TriV& tr, GetGlobal 
         const double mag = fabs(N.x * d.x) + fabs(N.y * d.y) + fabs(N.z * d.z);
         bool cull;
         if (fabs(dcr) > 1e-12 * mag) cull = dcr < 0;
-        else cull = dot(d, ld3(S.tri_gnormal + (size_t)global_index() * 3)) > 0;
+        else cull = dot(d, ld3(gnormal + (size_t)global_index() * 3)) > 0;
         if (cull) return false;
     }
-    if (STATS) cnt.tris++;
+    if (STATS) n_tests++;
     if (fabs(dcr) < 1e-12) return false;
     const DV H = o - A;
     const double gn = dot(N, H);
@@ -107,7 +150,7 @@ QD_DEV bool tri_test(const DScene& S, uint32_t flags, const TriV& tr, GetGlobal 
     return true;
 }
 
-struct MHit { double dist, l2, l3; int tri; };
+struct MHit { double dist, l2, l3; int tri; uint32_t n_nodes, n_tris; };
 
 // Closest hit of one mesh (object space).  Replaces Mesh::Intersect(ray, info) src/mesh.cpp:30-56 and the
 // recursive KD walk :58-92.
@@ -115,10 +158,13 @@ struct MHit { double dist, l2, l3; int tri; };
 // the node's closest hit satisfies Sqr(distance) < targetDistSq.  The closest hit satisfies it iff ANY accepted
 // candidate does (x -> Sqr(x / len) is monotone), so the walk stops at the first such candidate and never looks
 // beyond the light.
+// Returns tri = -1 for a miss.  n_nodes / n_tris are filled in the counting build.
 template <bool STATS>
-QD_DEV bool mesh_intersect(const DScene& S, int mesh_idx, const DV& o, const DV& d, bool any, double target, double rlen,
-                           MHit& out, Counters& cnt) {
-    const qd_mesh& m = S.meshes[mesh_idx];
+__device__ __attribute__((noinline)) MHit mesh_query(MeshData D, int mesh_idx, DV o, DV d, bool any, double target, double rlen) {
+    MHit out;
+    out.dist = kInf; out.l2 = 0; out.l3 = 0; out.tri = -1; out.n_nodes = 0; out.n_tris = 0;
+    const QD_GLOBAL qd_mesh& m = ((const QD_GLOBAL qd_mesh*)D.meshes)[mesh_idx];
+    const gp_f64 gnormal = (gp_f64)D.tri_gnormal;
     const DV md = -d;
     // slab interval of the ray in the mesh box, padded like BBox::IsInside's 1e-6 (src/bbox.cpp:24-31)
     double t0 = 0., t1 = kInf;
@@ -127,87 +173,108 @@ QD_DEV bool mesh_intersect(const DScene& S, int mesh_idx, const DV& o, const DV&
     for (int a = 0; a < 3; ++a) {
         const double oa = comp(o, a), da = comp(d, a);
         const double lo = m.bbox_min[a] - 1e-6, hi = m.bbox_max[a] + 1e-6;
-        if (da == 0.) { if (oa < lo || oa > hi) return false; continue; }
+        if (da == 0.) { if (oa < lo || oa > hi) return out; continue; }
         double ta = (lo - oa) * comp(inv, a), tb = (hi - oa) * comp(inv, a);
         if (ta > tb) { const double s = ta; ta = tb; tb = s; }
         t0 = fmax(t0, ta); t1 = fmin(t1, tb);
     }
     if (any) t1 = fmin(t1, dsqrt(target) * rlen * (1. + 1e-9) + 1e-7);   // nothing beyond the light matters
-    if (t0 > t1) return false;
+    if (t0 > t1) return out;
 
     const uint32_t flags = m.flags, tri_first = m.tri_first;
     double best = kInf, l2 = 0, l3 = 0;
     int tri = -1;
+    uint32_t n_nodes = 0, n_tris = 0;
     if (m.kd_root < 0) {
         const uint32_t n_tri = m.tri_count;
+        const gp_f64 tv = (gp_f64)D.tri_verts;
         for (uint32_t i = 0; i < n_tri; ++i) {
-            const TriV tr = ld_tri(S.tri_verts + (size_t)(tri_first + i) * 9);
-            if (tri_test<STATS>(S, flags, tr, [&]() { return tri_first + i; }, o, d, md, best, l2, l3, cnt)) {
+            const TriV tr = ld_tri(tv + (size_t)(tri_first + i) * 9);
+            if (tri_test<STATS>(gnormal, flags, tr, [&]() { return tri_first + i; }, o, d, md, best, l2, l3, n_tris)) {
                 tri = (int)i;
                 if (any && sqr(best / rlen) < target) break;
             }
         }
     } else {
-        if (STATS) cnt.mesh_queries++;
+        // Traversal as one loop with one trip to memory per iteration.  A lane is either at a node (fetch 16
+        // bytes, step down or open a leaf) or inside a leaf (fetch one triangle, test it); both kinds of lanes
+        // issue their loads before anybody waits, so lanes at different stages of their walk share every trip
+        // instead of waiting for each other at leaf boundaries.  The top of the far-child stack is kept in
+        // registers: a pop re-fills it from scratch without anything waiting on that load.
         uint32_t stk_node[kKdStack];
         double stk_t[kKdStack];
-        int sp = 0;
+        int sp = 0;                                   // entries in use; entry sp-1 lives in top_*, the rest in stk_*[0 .. sp-2]
+        uint32_t top_node = 0;
+        double top_t = 0.;
         uint32_t node = (uint32_t)m.kd_root;
+        uint32_t ref = 0, left = 0;                   // inside a leaf while left != 0: next leaf reference, references left
+        uint32_t hit_ref = 0xffffffffu;
         double tmin = t0, tmax = t1;
-        bool done = false;
-        while (!done) {
-            KdNode n = ld_kdnode(S, node);
-            if (STATS) cnt.kd_nodes++;
-            uint32_t axis = n.meta & 3u;
-            while (axis != 3u) {
-                const uint32_t left = n.meta >> 2;
-                const double oa = comp(o, (int)axis);
-                const double t = (n.split - oa) * comp(inv, (int)axis);
-                // near child = the side the origin is on (src/mesh.cpp:75-77: right iff start > split); an origin
-                // exactly on the plane belongs to the side the ray travels into.  The sign of t is exact.
-                const bool right_first = oa > n.split || (oa == n.split && comp(d, (int)axis) > 0);
-                const uint32_t near_c = left + (right_first ? 1u : 0u), far_c = left + (right_first ? 0u : 1u);
-                const double slack = 1e-7 + 1e-9 * fabs(t);
-                if (t > tmax + slack || t <= 0) {
-                    node = near_c;                                      // plane beyond the interval, or at/behind the origin
-                } else if (t < tmin - slack) {
-                    node = far_c;                                       // crossed before the interval starts
-                } else {                                                // (also taken when t is NaN: ray inside the plane)
-                    if (sp < kKdStack) { stk_node[sp] = far_c; stk_t[sp] = tmax; ++sp; }
-                    node = near_c;
-                    tmax = (t == t) ? fmin(tmax, t + slack) : tmax;
-                }
-                n = ld_kdnode(S, node);
-                if (STATS) cnt.kd_nodes++;
-                axis = n.meta & 3u;
-            }
-            const uint32_t first = n.meta >> 2, count = n.count;
-            if (count) {
-                // the leaf's triangles are contiguous in leaf_verts: fetch triangle i+1 while testing triangle i
-                const double* tv = S.leaf_verts + (size_t)first * 9;
-                TriV cur = ld_tri(tv);
-                for (uint32_t i = 0; i < count; ++i) {
-                    TriV nxt = cur;
-                    if (i + 1 < count) nxt = ld_tri(tv + (size_t)(i + 1) * 9);
-                    if (tri_test<STATS>(S, flags, cur, [&]() { return S.leaf_tris[first + i]; }, o, d, md, best, l2, l3, cnt)) {
-                        tri = (int)(S.leaf_tris[first + i] - tri_first);
-                        if (any && sqr(best / rlen) < target) { done = true; break; }
+        const uint32_t dpos = (d.x > 0 ? 1u : 0u) | (d.y > 0 ? 2u : 0u) | (d.z > 0 ? 4u : 0u);
+        const gp_u32x4 kd = (gp_u32x4)D.kd_nodes;
+        const gp_f64 leaf_verts = (gp_f64)D.leaf_verts;
+        const gp_u32 leaf_tris = (gp_u32)D.leaf_tris;
+        u32x4 nraw = {0u, 0u, 3u, 0u};
+        TriV tr;
+        tr.A = tr.AB = tr.AC = mk(0., 0., 0.);
+        bool alive = true;
+        while (alive) {
+            const bool in_leaf = left != 0u;
+            if (in_leaf) tr = ld_tri(leaf_verts + (size_t)ref * 9);
+            else nraw = kd[node];
+            asm volatile("" : "+v"(nraw), "+v"(tr.A.x), "+v"(tr.A.y), "+v"(tr.A.z), "+v"(tr.AB.x), "+v"(tr.AB.y), "+v"(tr.AB.z),
+                              "+v"(tr.AC.x), "+v"(tr.AC.y), "+v"(tr.AC.z));
+            bool leaf_done = false;
+            if (!in_leaf) {
+                const KdNode n = kd_unpack(nraw);
+                if (STATS) n_nodes++;
+                const uint32_t axis = n.meta & 3u;
+                if (axis != 3u) {
+                    // near child = the side the origin is on (src/mesh.cpp:75-77: right iff start > split); an origin
+                    // exactly on the plane belongs to the side the ray travels into.  The sign of t is exact.
+                    const uint32_t lc = n.meta >> 2;
+                    const double oa = pick(o, axis);
+                    const double t = (n.split - oa) * pick(inv, axis);
+                    const bool right_first = oa > n.split || (oa == n.split && ((dpos >> axis) & 1u));
+                    const uint32_t near_c = lc + (right_first ? 1u : 0u), far_c = lc + (right_first ? 0u : 1u);
+                    const double slack = 1e-7 + 1e-9 * fabs(t);
+                    if (t > tmax + slack || t <= 0) node = near_c;          // plane beyond the interval, or at/behind the origin
+                    else if (t < tmin - slack) node = far_c;                // crossed before the interval starts
+                    else {                                                  // (also taken when t is NaN: ray inside the plane)
+                        if (sp <= kKdStack) {
+                            if (sp > 0) { stk_node[sp - 1] = top_node; stk_t[sp - 1] = top_t; }
+                            top_node = far_c; top_t = tmax; ++sp;
+                        }
+                        node = near_c;
+                        tmax = (t == t) ? fmin(tmax, t + slack) : tmax;
                     }
-                    cur = nxt;
+                } else {
+                    ref = n.meta >> 2; left = n.count;
+                    leaf_done = left == 0u;
+                }
+            } else {
+                if (tri_test<STATS>(gnormal, flags, tr, [&]() { return leaf_tris[ref]; }, o, d, md, best, l2, l3, n_tris)) {
+                    hit_ref = ref;
+                    if (any && sqr(best / rlen) < target) alive = false;
+                }
+                ++ref; --left;
+                leaf_done = left == 0u;
+            }
+            if (leaf_done && alive) {
+                // front-to-back: a hit inside this leaf's interval cannot be beaten by later leaves
+                if (hit_ref != 0xffffffffu && best <= tmax - (2e-7 + 2e-9 * fabs(tmax))) alive = false;
+                else if (sp == 0) alive = false;
+                else {
+                    node = top_node; tmin = tmax; tmax = top_t;
+                    --sp;
+                    if (sp > 0) { top_node = stk_node[sp - 1]; top_t = stk_t[sp - 1]; }
                 }
             }
-            // front-to-back: a hit inside this leaf's interval cannot be beaten by later leaves
-            if (tri >= 0 && best <= tmax - (2e-7 + 2e-9 * fabs(tmax))) break;
-            if (sp == 0) break;
-            --sp;
-            node = stk_node[sp];
-            tmin = tmax;
-            tmax = stk_t[sp];
         }
+        if (hit_ref != 0xffffffffu) tri = (int)(leaf_tris[hit_ref] - tri_first);
     }
-    if (tri < 0) return false;
-    out.dist = best; out.tri = tri; out.l2 = l2; out.l3 = l3;
-    return true;
+    out.dist = best; out.tri = tri; out.l2 = l2; out.l3 = l3; out.n_nodes = n_nodes; out.n_tris = n_tris;
+    return out;
 }
 
 // Shading data of a mesh hit (src/mesh.cpp:141-163), evaluated once for the winner.

@@ -30,7 +30,7 @@ QD_DEV double len(const DV& a) { return dsqrt(a.x * a.x + a.y * a.y + a.z * a.z)
 QD_DEV DV normalize(DV a) { const double m = 1. / len(a); a.x *= m; a.y *= m; a.z *= m; return a; }
 QD_DEV double comp(const DV& a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 QD_DEV double sqr(double a) { return a * a; }
-QD_DEV DV ld3(const double* p) { return mk(p[0], p[1], p[2]); }
+template <class P> QD_DEV DV ld3(P p) { return mk(p[0], p[1], p[2]); }
 QD_DEV DV mul_mat(const DV& v, const double* m) {
     return mk(v.x * m[0] + v.y * m[3] + v.z * m[6], v.x * m[1] + v.y * m[4] + v.z * m[7], v.x * m[2] + v.y * m[5] + v.z * m[8]);
 }

@@ -18,6 +18,7 @@
 
 #include "dshade.h"
 #include "qdtrace.h"
+#include "kdrefine.h"
 
 using namespace qd;
 
@@ -115,20 +116,25 @@ QD_DEV int trace_nodes(const DScene& S, const DV& o, const DV& d, bool shadow, d
             if (shadow || best_node < 0) break;
             final_pass = true; i = (uint32_t)best_node;
         }
+        const unsigned long long ta0 = QD_STAMP();
         const qd_node& n = S.nodes[i];
         const ObjRay r = to_object(n, o, d);
         const qd_geom g = S.geoms[n.geom];
         double dist = 0, c_l2 = 0, c_l3 = 0;
         int c_tri = -1;
         bool got;
+        const unsigned long long ta1 = QD_STAMP();
+        cnt.t_a += ta1 - ta0;
         if (g.type == QD_GEOM_MESH) {
             if (final_pass) {
                 hit.dist = w_dist; hit.ip = r.o + r.d * w_dist; hit.tri = w_tri; hit.mesh = g.a; hit.l2 = w_l2; hit.l3 = w_l3;
                 break;
             }
-            MHit mh;
-            got = mesh_intersect<STATS>(S, g.a, r.o, r.d, shadow, target, r.len, mh, cnt);
+            const MHit mh = mesh_query<STATS>(mesh_data(S), g.a, r.o, r.d, shadow, target, r.len);
+            got = mh.tri >= 0;
             if (got) { dist = mh.dist; c_tri = mh.tri; c_l2 = mh.l2; c_l3 = mh.l3; }
+            if (STATS) { cnt.kd_nodes += mh.n_nodes; cnt.tris += mh.n_tris; cnt.mesh_queries += mh.n_nodes ? 1u : 0u; }
+            cnt.t_b += QD_STAMP() - ta1;
         } else if (g.type == QD_GEOM_HEIGHTFIELD) {
             if (final_pass) { hf_finish(S, g.a, r.o, r.d, w_dist, hit); break; }
             got = hf_intersect(S, g.a, r.o, r.d, dist);
@@ -138,6 +144,7 @@ QD_DEV int trace_nodes(const DScene& S, const DV& o, const DV& d, bool shadow, d
             if (final_pass) { hit = h; break; }
             dist = h.dist;
         }
+        const unsigned long long ta2 = QD_STAMP();
         if (got) {
             const double dw = dist / r.len;
             if (shadow) {
@@ -333,8 +340,10 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
     const size_t gl = (size_t)blockIdx.x * 64 + lane;
     LaneQueue q;
     q.base = P.stack + gl; q.stride = P.n_lanes; q.cap = P.stack_cap; q.sp = 0; q.err = P.error_flag;
-    Counters cnt; cnt.kd_nodes = cnt.tris = cnt.mesh_queries = 0;
+    Counters cnt; cnt.kd_nodes = cnt.tris = cnt.mesh_queries = 0; cnt.t_desc = cnt.t_leaf = cnt.t_a = cnt.t_b = cnt.t_c = cnt.t_d = 0;
     uint32_t n_rays = 0, n_primary = 0, n_shadow = 0, n_killed = 0;
+    unsigned long long t_trace = 0, t_shade = 0, t_sched = 0;
+    const unsigned long long t_begin = QD_STAMP();
 
     uint32_t unit = 0, unit_next = 64;     // wave-uniform: current unit and its first unassigned pixel
     bool pool_empty = false;
@@ -343,6 +352,7 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
     Col acc = mkc(0, 0, 0);
 
     for (;;) {
+        const unsigned long long tp0 = QD_STAMP();
         if (have_px && q.sp == 0) {        // pixel finished: write it (vfb[y][x] = Raytrace(...), src/main.cpp:96)
             float* o = P.rgb + (P.mode == 0 ? (size_t)(out_idx / (uint32_t)P.rw) * P.pitch + (size_t)(out_idx % (uint32_t)P.rw) * 3
                                             : (size_t)out_idx * 3);
@@ -390,7 +400,11 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
         if (!shadow && depth > P.max_depth) { ++n_killed; continue; }          // src/main.cpp:20-21
         if (shadow) ++n_shadow; else ++n_rays;
         GHit h; double dw; float transp;
+        const unsigned long long tp1 = QD_STAMP();
+        t_sched += tp1 - tp0;
         const int node = trace_nodes<STATS>(S, t.o, t.d, shadow, t.aux0, transp, dw, h, cnt);
+        const unsigned long long tp2 = QD_STAMP();
+        t_trace += tp2 - tp1;
         if (shadow) {
             acc = acc + t.w * (float)((double)transp * t.aux1);
             continue;
@@ -423,7 +437,16 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
         } else {
             eval_leaf_shader(S, P, n.shader, t.w, 0, t, depth, info, acc, q);
         }
+        t_shade += QD_STAMP() - tp2;
     }
+#ifdef QD_PROFILE
+    if (P.stats && lane == 0) {   // diagnostic build: wave-cycle shares go to their own words, never into outputs
+        atomicAdd(&P.stats[8], QD_STAMP() - t_begin);
+        atomicAdd(&P.stats[9], t_sched); atomicAdd(&P.stats[10], t_trace); atomicAdd(&P.stats[11], t_shade);
+        atomicAdd(&P.stats[12], cnt.t_desc); atomicAdd(&P.stats[13], cnt.t_leaf);
+        atomicAdd(&P.stats[14], cnt.t_a); atomicAdd(&P.stats[15], cnt.t_b); atomicAdd(&P.stats[7], cnt.t_c); atomicAdd(&P.stats[6], cnt.t_d);
+    }
+#endif
 
     if (P.stats) {
         const uint32_t r = wave_sum(n_rays), p = wave_sum(n_primary), s = wave_sum(n_shadow), k = wave_sum(n_killed);
@@ -478,6 +501,8 @@ thread_local std::string g_err;
 int g_device = -1;
 int g_num_cu = 0;
 bool g_counting = false;
+int g_refine_leaf = 2;        // qd_set_kd_refine
+double g_refine_cost = 0.6;
 
 int set_err(const std::string& m) { g_err = m; return -1; }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
@@ -494,29 +519,31 @@ struct qd_scene {
     unsigned long long* stats = nullptr; // 8 counters
     int* error_flag = nullptr;
     uint32_t spawn0 = 1, spawn1 = 1;     // tasks queued per hit at depth 0 / deeper
+    uint64_t kd_nodes = 0, kd_refs = 0, kd_leaves = 0, kd_max_leaf = 0;   // device tree after refinement
 };
 
 namespace {
 
 // KD nodes re-ordered for the device: a node's two children and their four children share one 128-byte
-// block (8 slots of 16 bytes, 6 used), so a root-to-leaf walk touches a new cache line every second level.
-// Node contents and child adjacency (index, index + 1) are unchanged -- only positions move -- so the
-// traversal code is oblivious to the layout.  Leaf references become global triangle indices.
-void relayout_kd(const qd_scene_desc* d, std::vector<qd_kdnode>& out, std::vector<qd_mesh>& meshes, std::vector<uint32_t>& leaf_global) {
-    const qd_kdnode* src = d->kd_nodes;
-    leaf_global.assign(d->leaf_tris, d->leaf_tris + d->n_leaf_tris);
+// block (8 slots of 16 bytes, 6 used): slots 0/1 = the children, slots 2+2s/3+2s = the children of slot s.
+// mesh_intersect relies on this to fetch a slot-0/1 node together with its children in one round trip.
+// Child adjacency (index, index + 1) is kept.  Leaf references become global triangle indices.
+void relayout_kd(const qd_refine::Result& R, std::vector<qd_kdnode>& out, std::vector<qd_mesh>& meshes, std::vector<uint32_t>& leaf_global) {
+    const qd_kdnode* src = R.nodes.data();
+    leaf_global = R.refs;
     const qd_kdnode empty{0., 3u, 0u};   // unused slot = empty leaf
     struct Item { uint32_t src_pair; size_t dst_parent; };
     std::vector<Item> stack;
-    for (qd_mesh& m : meshes) {
+    for (size_t mi = 0; mi < meshes.size(); ++mi) {
+        qd_mesh& m = meshes[mi];
         if (m.kd_root < 0) continue;
         auto mark_leaf = [&](const qd_kdnode& n) {
             const size_t first = n.meta >> 2;
-            for (size_t r = first; r < first + n.count; ++r) leaf_global[r] = d->leaf_tris[r] + m.tri_first;
+            for (size_t r = first; r < first + n.count; ++r) leaf_global[r] = R.refs[r] + m.tri_first;
         };
-        const size_t rb = out.size();
-        out.resize(rb + 8, empty);
-        out[rb] = src[m.kd_root];
+        const size_t rb = out.size() + 7;    // the root sits alone in the last slot of a block: slots 0/1 promise children in slots 2..5
+        out.resize(rb + 1, empty);
+        out[rb] = src[R.roots[mi]];
         m.kd_root = (int32_t)rb;
         if ((out[rb].meta & 3u) == 3u) { mark_leaf(out[rb]); continue; }
         stack.push_back(Item{out[rb].meta >> 2, rb});
@@ -609,6 +636,21 @@ extern "C" int qd_init(int device) {
 extern "C" void qd_shutdown(void) { g_device = -1; }
 
 extern "C" int qd_set_counting(int on) { g_counting = on != 0; return 0; }
+
+extern "C" int qd_set_kd_refine(int max_leaf_tris, double step_cost) {
+    if (max_leaf_tris < 0 || !(step_cost > 0.)) return set_err("qd_set_kd_refine: max_leaf_tris >= 0 and step_cost > 0 required");
+    g_refine_leaf = max_leaf_tris; g_refine_cost = step_cost;
+    return 0;
+}
+
+extern "C" int qd_scene_kd_info(const qd_scene* s, uint64_t* nodes, uint64_t* leaf_refs, uint64_t* leaves, uint64_t* max_leaf) {
+    if (!s) return set_err("qd_scene_kd_info: null scene");
+    if (nodes) *nodes = s->kd_nodes;
+    if (leaf_refs) *leaf_refs = s->kd_refs;
+    if (leaves) *leaves = s->kd_leaves;
+    if (max_leaf) *max_leaf = s->kd_max_leaf;
+    return 0;
+}
 
 extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     if (!desc || !out) return set_err("qd_scene_create: null argument");
@@ -706,7 +748,17 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     std::vector<qd_kdnode> kd_blocked;
     std::vector<qd_mesh> meshes_dev(desc->meshes, desc->meshes + desc->n_meshes);
     std::vector<uint32_t> leaf_global;
-    relayout_kd(desc, kd_blocked, meshes_dev, leaf_global);
+    {
+        qd_refine::Options opt;
+        opt.max_leaf = g_refine_leaf;
+        opt.cost_step = g_refine_cost;
+        opt.max_depth = kKdStack - 2;
+        qd_refine::Result refined;
+        qd_refine::refine(desc, opt, refined);
+        if (refined.refs.size() >= (1u << 30) || refined.nodes.size() >= (1u << 29)) { delete s; return set_err("qd_scene_create: KD tree too large for 30-bit indices"); }
+        relayout_kd(refined, kd_blocked, meshes_dev, leaf_global);
+        s->kd_nodes = refined.nodes.size(); s->kd_refs = refined.refs.size(); s->kd_leaves = refined.leaves; s->kd_max_leaf = refined.max_leaf;
+    }
     if (kd_blocked.size() >= (1u << 30)) { delete s; return set_err("qd_scene_create: KD tree too large for 30-bit node indices"); }
     rc |= upload(s, meshes_dev.data(), meshes_dev.size(), &d.meshes);
     rc |= upload(s, desc->hfields, desc->n_hfields, &d.hfields);
@@ -744,7 +796,7 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     s->spawn0 = spawn0; s->spawn1 = spawn1;
     s->n_lanes = (uint32_t)(g_num_cu > 0 ? g_num_cu : 256) * kWavesPerCU * 64u;
     if (!rc && hipMalloc((void**)&s->queue_ctr, 8 * sizeof(uint32_t)) != hipSuccess) rc = set_err("hipMalloc(queue counters) failed");
-    if (!rc && hipMalloc((void**)&s->stats, 8 * sizeof(unsigned long long)) != hipSuccess) rc = set_err("hipMalloc(stats) failed");
+    if (!rc && hipMalloc((void**)&s->stats, 16 * sizeof(unsigned long long)) != hipSuccess) rc = set_err("hipMalloc(stats) failed");
     if (!rc && hipMalloc((void**)&s->error_flag, sizeof(int)) != hipSuccess) rc = set_err("hipMalloc(error flag) failed");
     if (!rc && hipMemset(s->error_flag, 0, sizeof(int)) != hipSuccess) rc = set_err("hipMemset failed");
     if (!rc) rc = ensure_stack(s, desc->settings.max_trace_depth);
@@ -792,7 +844,7 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
     }
     P.rgb = d_rgb; P.pitch = (size_t)rw * 3; P.hit_node = d_hn; P.hit_tri = d_ht; P.hit_dist = d_hd;
     P.stats = s->stats;
-    TRY2(hipMemsetAsync(s->stats, 0, 8 * sizeof(unsigned long long), nullptr));
+    TRY2(hipMemsetAsync(s->stats, 0, 16 * sizeof(unsigned long long), nullptr));
     TRY2(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
     TRY2(hipEventCreate(&e0)); TRY2(hipEventCreate(&e1));
     TRY2(hipEventRecord(e0, nullptr));
@@ -811,8 +863,11 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
         TRY2(hipMemcpy(hit_dist, d_hd, npx * sizeof(double), hipMemcpyDeviceToHost));
     }
     if (stats) {
-        unsigned long long h[8];
+        unsigned long long h[16];
         TRY2(hipMemcpy(h, s->stats, sizeof h, hipMemcpyDeviceToHost));
+#ifdef QD_PROFILE
+        fprintf(stderr, "[qd profile] wave-cycles total %llu sched %llu trace %llu shade %llu | descent %llu leaf %llu | xform %llu mesh %llu setup %llu pop %llu\n", h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[7], h[6]);
+#endif
         stats->rays = h[0]; stats->primary_rays = h[1]; stats->shadow_rays = h[2]; stats->depth_killed = h[3];
         stats->kd_nodes_visited = h[4]; stats->tris_tested = h[5]; stats->mesh_queries = h[6];
         stats->kernel_ms = ms;

@@ -35,6 +35,8 @@ def lib():
                                             C.c_void_p, C.c_void_p, C.c_void_p]
         L.qd_untile_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.qd_quantize_bgr8_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
+        L.qd_set_kd_refine.argtypes = [C.c_int, C.c_double]
+        L.qd_scene_kd_info.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
         for name in abi.QDTRACE_SYMBOLS:
             if name not in ("qd_last_error", "qd_shutdown", "qd_scene_destroy"):
                 getattr(L, name).restype = C.c_int
@@ -55,6 +57,11 @@ def init(device=0):
 
 def set_counting(on):
     _check(lib().qd_set_counting(1 if on else 0), "qd_set_counting")
+
+
+def set_kd_refine(max_leaf_tris=2, step_cost=0.6):
+    """Leaf refinement of the device copy of KD trees for scenes created afterwards (0 = caller's tree unchanged)."""
+    _check(lib().qd_set_kd_refine(max_leaf_tris, step_cost), "qd_set_kd_refine")
 
 
 class DeviceScene:
@@ -94,6 +101,11 @@ class DeviceScene:
 
     def check(self):
         _check(lib().qd_scene_check(self._h), "qd_scene_check")
+
+    def kd_info(self):
+        v = [C.c_uint64() for _ in range(4)]
+        _check(lib().qd_scene_kd_info(self._h, *[C.byref(x) for x in v]), "qd_scene_kd_info")
+        return dict(zip(("nodes", "leaf_refs", "leaves", "max_leaf"), (int(x.value) for x in v)))
 
     def close(self):
         if self._h:

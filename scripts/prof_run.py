@@ -1,0 +1,12 @@
+"""Diagnostic: render one frame of the bench scene through qd_render (prints [qd profile] shares with the QD_PROFILE build)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracing_amd import device, host
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2240
+s = host.Scene.synthetic(n, 42, 3840, 2160, 8, os.path.join(ROOT, "tests/golden/data/env/forest"))
+device.init(0)
+ds = device.DeviceScene(s)
+for i in range(2):
+    rgb, _, st = ds.render()
+    print({k: st[k] for k in ("rays", "kernel_ms")}, flush=True)
