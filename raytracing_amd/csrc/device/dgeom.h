@@ -63,6 +63,10 @@ struct Counters {
 #endif
 
 constexpr int kKdStack = 72;
+#ifndef QD_TRI_BATCH
+#define QD_TRI_BATCH 16
+#endif
+constexpr int kTriBatch = QD_TRI_BATCH;   // lanes waiting inside a leaf before the wave runs a triangle pass
 
 // KD node as one 16-byte load (hipMalloc'd arrays are 256-byte aligned, nodes are 16 bytes)
 struct KdNode { double split; uint32_t meta, count; };
@@ -214,51 +218,77 @@ __device__ __attribute__((noinline)) MHit mesh_query(MeshData D, int mesh_idx, D
         const gp_u32x4 kd = (gp_u32x4)D.kd_nodes;
         const gp_f64 leaf_verts = (gp_f64)D.leaf_verts;
         const gp_u32 leaf_tris = (gp_u32)D.leaf_tris;
-        u32x4 nraw = {0u, 0u, 3u, 0u};
+        u32x4 nraw = {0u, 0u, 3u, 0u}, k0raw = nraw, k1raw = nraw;
         TriV tr;
-        tr.A = tr.AB = tr.AC = mk(0., 0., 0.);
         bool alive = true;
-        while (alive) {
-            const bool in_leaf = left != 0u;
-            if (in_leaf) tr = ld_tri(leaf_verts + (size_t)ref * 9);
-            else nraw = kd[node];
-            asm volatile("" : "+v"(nraw), "+v"(tr.A.x), "+v"(tr.A.y), "+v"(tr.A.z), "+v"(tr.AB.x), "+v"(tr.AB.y), "+v"(tr.AB.z),
-                              "+v"(tr.AC.x), "+v"(tr.AC.y), "+v"(tr.AC.z));
-            bool leaf_done = false;
-            if (!in_leaf) {
-                const KdNode n = kd_unpack(nraw);
-                if (STATS) n_nodes++;
-                const uint32_t axis = n.meta & 3u;
-                if (axis != 3u) {
-                    // near child = the side the origin is on (src/mesh.cpp:75-77: right iff start > split); an origin
-                    // exactly on the plane belongs to the side the ray travels into.  The sign of t is exact.
-                    const uint32_t lc = n.meta >> 2;
-                    const double oa = pick(o, axis);
-                    const double t = (n.split - oa) * pick(inv, axis);
-                    const bool right_first = oa > n.split || (oa == n.split && ((dpos >> axis) & 1u));
-                    const uint32_t near_c = lc + (right_first ? 1u : 0u), far_c = lc + (right_first ? 0u : 1u);
-                    const double slack = 1e-7 + 1e-9 * fabs(t);
-                    if (t > tmax + slack || t <= 0) node = near_c;          // plane beyond the interval, or at/behind the origin
-                    else if (t < tmin - slack) node = far_c;                // crossed before the interval starts
-                    else {                                                  // (also taken when t is NaN: ray inside the plane)
-                        if (sp <= kKdStack) {
-                            if (sp > 0) { stk_node[sp - 1] = top_node; stk_t[sp - 1] = top_t; }
-                            top_node = far_c; top_t = tmax; ++sp;
-                        }
-                        node = near_c;
-                        tmax = (t == t) ? fmin(tmax, t + slack) : tmax;
+        bool leaf_done = false;
+        // One node: an inner node picks the child to continue in and queues the other one when the ray's interval
+        // straddles the plane; a leaf opens its reference list.  Returns true for an inner node.
+        // near child = the side the origin is on (src/mesh.cpp:75-77: right iff start > split); an origin exactly
+        // on the plane belongs to the side the ray travels into.  The sign of t is exact.
+        auto visit = [&](const KdNode& n) -> bool {
+            if (STATS) n_nodes++;
+            const uint32_t axis = n.meta & 3u;
+            if (axis == 3u) {
+                ref = n.meta >> 2; left = n.count;
+                leaf_done = left == 0u;
+                return false;
+            }
+            const uint32_t lc = n.meta >> 2;
+            const double oa = pick(o, axis);
+            const double t = (n.split - oa) * pick(inv, axis);
+            const bool right_first = oa > n.split || (oa == n.split && ((dpos >> axis) & 1u));
+            const uint32_t near_c = lc + (right_first ? 1u : 0u), far_c = lc + (right_first ? 0u : 1u);
+            const double slack = 1e-7 + 1e-9 * fabs(t);
+            if (t > tmax + slack || t <= 0) node = near_c;          // plane beyond the interval, or at/behind the origin
+            else if (t < tmin - slack) node = far_c;                // crossed before the interval starts
+            else {                                                  // (also taken when t is NaN: ray inside the plane)
+                if (sp <= kKdStack) {
+                    if (sp > 0) { stk_node[sp - 1] = top_node; stk_t[sp - 1] = top_t; }
+                    top_node = far_c; top_t = tmax; ++sp;
+                }
+                node = near_c;
+                tmax = (t == t) ? fmin(tmax, t + slack) : tmax;
+            }
+            return true;
+        };
+        // Every pass of the loop is either a node pass or a triangle pass for the whole wave (a uniform branch, so
+        // the other kind's instructions are not issued at all).  Lanes that have opened a leaf wait until
+        // kTriBatch lanes are in that state, or nobody is left walking nodes: the ~150-instruction triangle test
+        // then runs with many lanes active instead of in every pass for the few lanes that happen to need it.
+        for (;;) {
+            const unsigned long long m_alive = __ballot(alive);
+            if (!m_alive) break;
+            const bool in_leaf = alive && left != 0u;
+            const int n_leaf = __popcll(__ballot(in_leaf)), n_node = __popcll(m_alive) - n_leaf;
+            const bool tri_pass = n_leaf >= kTriBatch || n_node == 0;
+#ifdef QD_PROFILE
+            {   // diagnostic: lane iterations in n_nodes, wave iterations in n_tris (credited to the first live lane)
+                if (alive && (in_leaf == tri_pass)) n_nodes++;
+                if (alive && (unsigned)(__ffsll((long long)m_alive) - 1) == (threadIdx.x & 63u)) n_tris++;
+            }
+#endif
+            leaf_done = false;
+            if (tri_pass) {
+                if (in_leaf) {
+                    tr = ld_tri(leaf_verts + (size_t)ref * 9);
+                    if (tri_test<STATS>(gnormal, flags, tr, [&]() { return leaf_tris[ref]; }, o, d, md, best, l2, l3, n_tris)) {
+                        hit_ref = ref;
+                        if (any && sqr(best / rlen) < target) alive = false;
                     }
-                } else {
-                    ref = n.meta >> 2; left = n.count;
+                    ++ref; --left;
                     leaf_done = left == 0u;
                 }
-            } else {
-                if (tri_test<STATS>(gnormal, flags, tr, [&]() { return leaf_tris[ref]; }, o, d, md, best, l2, l3, n_tris)) {
-                    hit_ref = ref;
-                    if (any && sqr(best / rlen) < target) alive = false;
-                }
-                ++ref; --left;
-                leaf_done = left == 0u;
+            } else if (alive && !in_leaf) {
+                // The device layout (relayout_kd) keeps a node in slot 0/1 of a 128-byte block together with its two
+                // children (slots 2+2s, 3+2s): the same trip fetches the node and both children, so two tree levels
+                // are decided per trip.  Nodes in slots 2..5 (and the root) have their children in another block.
+                const uint32_t slot = node & 7u;
+                const bool pair = slot < 2u;
+                nraw = kd[node];
+                if (pair) { const uint32_t kb = (node & ~7u) + 2u + 2u * slot; k0raw = kd[kb]; k1raw = kd[kb + 1u]; }
+                asm volatile("" : "+v"(nraw), "+v"(k0raw), "+v"(k1raw));
+                if (visit(kd_unpack(nraw)) && pair) visit(kd_unpack((node & 1u) ? k1raw : k0raw));   // children sit at an even slot and the next one
             }
             if (leaf_done && alive) {
                 // front-to-back: a hit inside this leaf's interval cannot be beaten by later leaves

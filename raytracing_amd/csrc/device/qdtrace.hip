@@ -134,6 +134,9 @@ QD_DEV int trace_nodes(const DScene& S, const DV& o, const DV& d, bool shadow, d
             got = mh.tri >= 0;
             if (got) { dist = mh.dist; c_tri = mh.tri; c_l2 = mh.l2; c_l3 = mh.l3; }
             if (STATS) { cnt.kd_nodes += mh.n_nodes; cnt.tris += mh.n_tris; cnt.mesh_queries += mh.n_nodes ? 1u : 0u; }
+#ifdef QD_PROFILE
+            cnt.t_desc += mh.n_nodes; cnt.t_leaf += mh.n_tris;
+#endif
             cnt.t_b += QD_STAMP() - ta1;
         } else if (g.type == QD_GEOM_HEIGHTFIELD) {
             if (final_pass) { hf_finish(S, g.a, r.o, r.d, w_dist, hit); break; }
@@ -141,6 +144,7 @@ QD_DEV int trace_nodes(const DScene& S, const DV& o, const DV& d, bool shadow, d
         } else {
             GHit h;
             got = analytic_intersect(S, g, r.o, r.d, h);
+            cnt.t_c += QD_STAMP() - ta1;
             if (final_pass) { hit = h; break; }
             dist = h.dist;
         }
@@ -156,6 +160,7 @@ QD_DEV int trace_nodes(const DScene& S, const DV& o, const DV& d, bool shadow, d
                 best_dw = dw; best_node = (int)i; w_dist = dist; w_tri = c_tri; w_l2 = c_l2; w_l3 = c_l3;
             }
         }
+        cnt.t_d += QD_STAMP() - ta2;
         ++i;
     }
     return best_node;
@@ -440,10 +445,10 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
         t_shade += QD_STAMP() - tp2;
     }
 #ifdef QD_PROFILE
+    if (P.stats) { atomicAdd(&P.stats[12], cnt.t_desc); atomicAdd(&P.stats[13], cnt.t_leaf); }   // lane / wave iterations of the KD loop
     if (P.stats && lane == 0) {   // diagnostic build: wave-cycle shares go to their own words, never into outputs
         atomicAdd(&P.stats[8], QD_STAMP() - t_begin);
         atomicAdd(&P.stats[9], t_sched); atomicAdd(&P.stats[10], t_trace); atomicAdd(&P.stats[11], t_shade);
-        atomicAdd(&P.stats[12], cnt.t_desc); atomicAdd(&P.stats[13], cnt.t_leaf);
         atomicAdd(&P.stats[14], cnt.t_a); atomicAdd(&P.stats[15], cnt.t_b); atomicAdd(&P.stats[7], cnt.t_c); atomicAdd(&P.stats[6], cnt.t_d);
     }
 #endif
@@ -866,7 +871,7 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
         unsigned long long h[16];
         TRY2(hipMemcpy(h, s->stats, sizeof h, hipMemcpyDeviceToHost));
 #ifdef QD_PROFILE
-        fprintf(stderr, "[qd profile] wave-cycles total %llu sched %llu trace %llu shade %llu | descent %llu leaf %llu | xform %llu mesh %llu setup %llu pop %llu\n", h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[7], h[6]);
+        fprintf(stderr, "[qd profile] wave-cycles total %llu sched %llu trace %llu shade %llu | kd lane-iters %llu wave-iters %llu | xform %llu mesh %llu analytic %llu bookkeeping %llu\n", h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[7], h[6]);
 #endif
         stats->rays = h[0]; stats->primary_rays = h[1]; stats->shadow_rays = h[2]; stats->depth_killed = h[3];
         stats->kd_nodes_visited = h[4]; stats->tris_tested = h[5]; stats->mesh_queries = h[6];
