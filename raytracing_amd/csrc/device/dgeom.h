@@ -210,6 +210,8 @@ __device__ __attribute__((noinline)) MHit mesh_query(MeshData D, int mesh_idx, D
         int sp = 0;                                   // entries in use; entry sp-1 lives in top_*, the rest in stk_*[0 .. sp-2]
         uint32_t top_node = 0;
         double top_t = 0.;
+        // position in the tree: record index (28 bits) | sub << 30; sub 0 = the record's own node, 1 / 2 = only its
+        // left / right child (a far child queued from inside a record), see kdrefine.h for the record format
         uint32_t node = (uint32_t)m.kd_root;
         uint32_t ref = 0, left = 0;                   // inside a leaf while left != 0: next leaf reference, references left
         uint32_t hit_ref = 0xffffffffu;
@@ -218,44 +220,32 @@ __device__ __attribute__((noinline)) MHit mesh_query(MeshData D, int mesh_idx, D
         const gp_u32x4 kd = (gp_u32x4)D.kd_nodes;
         const gp_f64 leaf_verts = (gp_f64)D.leaf_verts;
         const gp_u32 leaf_tris = (gp_u32)D.leaf_tris;
-        u32x4 nraw = {0u, 0u, 3u, 0u}, k0raw = nraw, k1raw = nraw;
         TriV tr;
         bool alive = true;
         bool leaf_done = false;
-        // One node: an inner node picks the child to continue in and queues the other one when the ray's interval
-        // straddles the plane; a leaf opens its reference list.  Returns true for an inner node.
-        // near child = the side the origin is on (src/mesh.cpp:75-77: right iff start > split); an origin exactly
-        // on the plane belongs to the side the ray travels into.  The sign of t is exact.
-        auto visit = [&](const KdNode& n) -> bool {
+        // One split plane: returns the side (0 left, 1 right) to continue in and queues the other side's token when
+        // the ray's interval straddles the plane.  near side = the side the origin is on (src/mesh.cpp:75-77: right
+        // iff start > split); an origin exactly on the plane belongs to the side the ray travels into.  The sign of
+        // t is exact.
+        auto choose = [&](double split, uint32_t axis, uint32_t tok_left, uint32_t tok_right) -> uint32_t {
             if (STATS) n_nodes++;
-            const uint32_t axis = n.meta & 3u;
-            if (axis == 3u) {
-                ref = n.meta >> 2; left = n.count;
-                leaf_done = left == 0u;
-                return false;
-            }
-            const uint32_t lc = n.meta >> 2;
             const double oa = pick(o, axis);
-            const double t = (n.split - oa) * pick(inv, axis);
-            const bool right_first = oa > n.split || (oa == n.split && ((dpos >> axis) & 1u));
-            const uint32_t near_c = lc + (right_first ? 1u : 0u), far_c = lc + (right_first ? 0u : 1u);
+            const double t = (split - oa) * pick(inv, axis);
+            const uint32_t near_s = (oa > split || (oa == split && ((dpos >> axis) & 1u))) ? 1u : 0u;
             const double slack = 1e-7 + 1e-9 * fabs(t);
-            if (t > tmax + slack || t <= 0) node = near_c;          // plane beyond the interval, or at/behind the origin
-            else if (t < tmin - slack) node = far_c;                // crossed before the interval starts
-            else {                                                  // (also taken when t is NaN: ray inside the plane)
-                if (sp <= kKdStack) {
-                    if (sp > 0) { stk_node[sp - 1] = top_node; stk_t[sp - 1] = top_t; }
-                    top_node = far_c; top_t = tmax; ++sp;
-                }
-                node = near_c;
-                tmax = (t == t) ? fmin(tmax, t + slack) : tmax;
+            if (t > tmax + slack || t <= 0) return near_s;          // plane beyond the interval, or at/behind the origin
+            if (t < tmin - slack) return near_s ^ 1u;               // crossed before the interval starts
+            // (also reached when t is NaN: ray inside the plane)
+            if (sp <= kKdStack) {
+                if (sp > 0) { stk_node[sp - 1] = top_node; stk_t[sp - 1] = top_t; }
+                top_node = near_s ? tok_left : tok_right; top_t = tmax; ++sp;
             }
-            return true;
+            tmax = (t == t) ? fmin(tmax, t + slack) : tmax;
+            return near_s;
         };
         // Every pass of the loop is either a node pass or a triangle pass for the whole wave (a uniform branch, so
         // the other kind's instructions are not issued at all).  Lanes that have opened a leaf wait until
-        // kTriBatch lanes are in that state, or nobody is left walking nodes: the ~150-instruction triangle test
-        // then runs with many lanes active instead of in every pass for the few lanes that happen to need it.
+        // kTriBatch lanes are in that state, or nobody is left walking nodes.
         for (;;) {
             const unsigned long long m_alive = __ballot(alive);
             if (!m_alive) break;
@@ -280,15 +270,28 @@ __device__ __attribute__((noinline)) MHit mesh_query(MeshData D, int mesh_idx, D
                     leaf_done = left == 0u;
                 }
             } else if (alive && !in_leaf) {
-                // The device layout (relayout_kd) keeps a node in slot 0/1 of a 128-byte block together with its two
-                // children (slots 2+2s, 3+2s): the same trip fetches the node and both children, so two tree levels
-                // are decided per trip.  Nodes in slots 2..5 (and the root) have their children in another block.
-                const uint32_t slot = node & 7u;
-                const bool pair = slot < 2u;
-                nraw = kd[node];
-                if (pair) { const uint32_t kb = (node & ~7u) + 2u + 2u * slot; k0raw = kd[kb]; k1raw = kd[kb + 1u]; }
-                asm volatile("" : "+v"(nraw), "+v"(k0raw), "+v"(k1raw));
-                if (visit(kd_unpack(nraw)) && pair) visit(kd_unpack((node & 1u) ? k1raw : k0raw));   // children sit at an even slot and the next one
+                const uint32_t rec = node & 0x3fffffffu, sub = node >> 30;
+                u32x4 ra = kd[2u * rec], rb = kd[2u * rec + 1u];          // one 32-byte record
+                asm volatile("" : "+v"(ra), "+v"(rb));
+                const uint32_t meta = rb.z;
+                if ((meta & 3u) == 3u) {                                  // leaf record
+                    if (STATS) n_nodes++;
+                    ref = ra.x; left = ra.y;
+                    leaf_done = left == 0u;
+                } else {
+                    const uint32_t c = sub ? sub - 1u
+                                           : choose(__hiloint2double((int)ra.y, (int)ra.x), meta & 3u, rec | (1u << 30), rec | (2u << 30));
+                    const uint32_t ac = (meta >> (2u + 2u * c)) & 3u;
+                    const uint32_t lo = c ? rb.x : ra.z, hi = c ? rb.y : ra.w;   // the child's plane, or first / count of a leaf child
+                    if (ac == 3u) {
+                        if (STATS) n_nodes++;
+                        ref = lo; left = hi;
+                        leaf_done = left == 0u;
+                    } else {
+                        const uint32_t cb = ((meta >> 6) << 2) + 2u * c;
+                        node = cb + choose(__hiloint2double((int)hi, (int)lo), ac, cb, cb + 1u);
+                    }
+                }
             }
             if (leaf_done && alive) {
                 // front-to-back: a hit inside this leaf's interval cannot be beaten by later leaves

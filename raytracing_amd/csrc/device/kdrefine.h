@@ -1,20 +1,27 @@
-// Host-side refinement of the caller's KD tree, run once in qd_scene_create.
+// Host-side construction of the DEVICE KD tree, run once in qd_scene_create.
 //
-// The reference stops splitting at 20 triangles per leaf (TRIANGLES_PER_LEAF, src/constants.h:14,
-// src/mesh.cpp:218) because a triangle test is cheap next to a recursive box-gated descent on a CPU.
-// On the device the balance is the other way round: a triangle test is 72 bytes of gathered f64 data
-// and ~100 f64 instructions, a descent step is one 16-byte load.  So every leaf of the caller's tree
-// is split further with a surface-area heuristic until splitting stops paying.  The closest hit of a
-// ray does not depend on how the triangles are grouped (SURVEY.md section 8(f).3 asks for exactly
-// this), only an exact distance tie between two different triangles can resolve differently.
+// Input: the caller's tree (the reference's builder, src/mesh.cpp:216-432, mirrored by libqdhost).
+// Output: a tree over the same triangles that the trace kernel walks:
+//  1. Every split plane and every leaf list of the caller's tree is kept.
+//  2. The reference stops splitting at 20 triangles per leaf (TRIANGLES_PER_LEAF, src/constants.h:14,
+//     src/mesh.cpp:218) because a triangle test is cheap next to a recursive box-gated descent on a CPU.  On
+//     the device a triangle test is 72 bytes of gathered f64 data and ~100 f64 instructions, a descent step
+//     is a fraction of a 16-byte load.  So every leaf is split further with a surface-area heuristic until
+//     splitting stops paying (SURVEY.md section 8(f).3 asks for a proper SAH for the large scene).
+//  3. The binary tree is packed into 32-byte records that hold two levels each (pack()).
+// The closest hit of a ray does not depend on how triangles are grouped; only an exact distance tie between
+// two different triangles can resolve differently.
 //
-// Classification of a triangle against a split plane follows the reference's PartitionTriangle
-// (src/mesh.cpp:412-432) on the triangle's bounds clipped to the node box: strictly below the plane
-// on some vertex -> left, strictly above -> right, lying in the plane -> left.
+// Classification of a triangle against a plane follows the reference's PartitionTriangle
+// (src/mesh.cpp:412-432) on the triangle's bounds clipped to the node box: below the plane somewhere -> left,
+// above somewhere -> right, lying in the plane -> left.
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -25,7 +32,7 @@ namespace qd_refine {
 struct Box { double lo[3], hi[3]; };
 
 struct Options {
-    int max_leaf = 2;          // leaves with at most this many triangles are never split
+    int max_leaf = 2;          // leaves with at most this many triangles are never split; 0 = keep the caller's leaves
     double cost_step = 0.6;    // cost of one descent step, in triangle tests
     int max_depth = 70;        // below the device traversal stack (kKdStack)
 };
@@ -37,22 +44,36 @@ inline double half_area(const Box& b) {
 
 struct TriBounds { double lo[3], hi[3]; };
 
-// subtree under one of the caller's leaves; node 0 is the subtree root, children of node i are at
-// nodes[i].meta >> 2 and +1 (local indices), leaves index into refs (local)
+inline TriBounds tri_bounds(const double* tri_verts, uint32_t global_tri, const Box& box) {
+    const double* v = tri_verts + (size_t)global_tri * 9;      // A, AB, AC
+    TriBounds b;
+    for (int a = 0; a < 3; ++a) {
+        const double p0 = v[a], p1 = v[a] + v[3 + a], p2 = v[a] + v[6 + a];
+        b.lo[a] = std::max(std::min(p0, std::min(p1, p2)), box.lo[a]);
+        b.hi[a] = std::min(std::max(p0, std::max(p1, p2)), box.hi[a]);
+        if (b.hi[a] < b.lo[a]) b.hi[a] = b.lo[a];              // bounds miss the box by rounding: keep a point
+    }
+    return b;
+}
+inline bool goes_left(double lo, double hi, double s) { return lo < s || (lo == s && hi == s); }
+inline bool goes_right(double hi, double s) { return hi > s; }
+
+// binary node: axis 0..2 inner (split, child = left child, right = child + 1); axis 3 leaf (first, count into refs)
+struct BNode { double split; uint32_t child; uint32_t count; uint8_t axis; };
+
 struct SubTree {
-    std::vector<qd_kdnode> nodes;
-    std::vector<uint32_t> refs;
+    std::vector<BNode> nodes;          // node 0 = subtree root; child indices local
+    std::vector<uint32_t> refs;        // mesh-local triangle indices
 };
 
 class Builder {
 public:
     Builder(const double* tri_verts, uint32_t tri_first, const Options& opt) : tv_(tri_verts), first_(tri_first), opt_(opt) {}
 
-    void build(SubTree& out, const Box& box, const uint32_t* tris, uint32_t n, int depth) {
+    void build(SubTree& out, const Box& box, const std::vector<uint32_t>& tris, int depth) {
         out.nodes.clear(); out.refs.clear();
-        out.nodes.push_back(qd_kdnode{0., 3u, 0u});
-        std::vector<uint32_t> list(tris, tris + n);
-        split(out, 0, box, list, depth);
+        out.nodes.push_back(BNode{0., 0u, 0u, 3});
+        split(out, 0, box, tris, depth);
     }
 
 private:
@@ -60,29 +81,17 @@ private:
     uint32_t first_;
     Options opt_;
 
-    TriBounds bounds(uint32_t t, const Box& box) const {
-        const double* v = tv_ + (size_t)(first_ + t) * 9;      // A, AB, AC
-        TriBounds b;
-        for (int a = 0; a < 3; ++a) {
-            const double p0 = v[a], p1 = v[a] + v[3 + a], p2 = v[a] + v[6 + a];
-            b.lo[a] = std::max(std::min(p0, std::min(p1, p2)), box.lo[a]);
-            b.hi[a] = std::min(std::max(p0, std::max(p1, p2)), box.hi[a]);
-            if (b.hi[a] < b.lo[a]) b.hi[a] = b.lo[a];          // bounds miss the box by rounding: keep a point
-        }
-        return b;
-    }
-
     void make_leaf(SubTree& out, size_t at, const std::vector<uint32_t>& list) {
-        out.nodes[at] = qd_kdnode{0., ((uint32_t)out.refs.size() << 2) | 3u, (uint32_t)list.size()};
+        out.nodes[at] = BNode{0., (uint32_t)out.refs.size(), (uint32_t)list.size(), 3};
         out.refs.insert(out.refs.end(), list.begin(), list.end());
     }
 
     void split(SubTree& out, size_t at, const Box& box, const std::vector<uint32_t>& list, int depth) {
         const uint32_t n = (uint32_t)list.size();
         const double area = half_area(box);
-        if ((int)n <= opt_.max_leaf || depth >= opt_.max_depth || !(area > 0.)) { make_leaf(out, at, list); return; }
+        if (opt_.max_leaf <= 0 || (int)n <= opt_.max_leaf || depth >= opt_.max_depth || !(area > 0.)) { make_leaf(out, at, list); return; }
         std::vector<TriBounds> tb(n);
-        for (uint32_t i = 0; i < n; ++i) tb[i] = bounds(list[i], box);
+        for (uint32_t i = 0; i < n; ++i) tb[i] = tri_bounds(tv_, first_ + list[i], box);
         double best_cost = (double)n;          // cost of staying a leaf
         int best_axis = -1;
         double best_split = 0.;
@@ -117,14 +126,14 @@ private:
         std::vector<uint32_t> left, right;
         for (uint32_t i = 0; i < n; ++i) {
             const double lo = tb[i].lo[best_axis], hi = tb[i].hi[best_axis];
-            if (lo < best_split || (lo == best_split && hi == best_split)) left.push_back(list[i]);
-            if (hi > best_split) right.push_back(list[i]);
+            if (goes_left(lo, hi, best_split)) left.push_back(list[i]);
+            if (goes_right(hi, best_split)) right.push_back(list[i]);
         }
         if (left.size() == n && right.size() == n) { make_leaf(out, at, list); return; }
         const size_t c = out.nodes.size();
-        out.nodes.push_back(qd_kdnode{0., 3u, 0u});
-        out.nodes.push_back(qd_kdnode{0., 3u, 0u});
-        out.nodes[at] = qd_kdnode{best_split, ((uint32_t)c << 2) | (uint32_t)best_axis, 0u};
+        out.nodes.push_back(BNode{0., 0u, 0u, 3});
+        out.nodes.push_back(BNode{0., 0u, 0u, 3});
+        out.nodes[at] = BNode{best_split, (uint32_t)c, 0u, (uint8_t)best_axis};
         Box bl = box, br = box;
         bl.hi[best_axis] = best_split; br.lo[best_axis] = best_split;
         split(out, c, bl, left, depth + 1);
@@ -132,94 +141,141 @@ private:
     }
 };
 
-struct Result {
-    std::vector<qd_kdnode> nodes;      // flat, children adjacent (index, index + 1), per-mesh roots in `roots`
+struct MeshTree {
+    std::vector<BNode> nodes;          // node 0 = root
     std::vector<uint32_t> refs;        // mesh-local triangle indices
-    std::vector<int32_t> roots;        // per mesh, -1 = no tree
-    uint64_t leaves = 0, max_leaf = 0;
-    uint32_t max_depth = 0;
 };
 
-// Copies every mesh's tree and re-splits its leaves.  `opt.max_leaf <= 0` copies the trees unchanged.
-inline void refine(const qd_scene_desc* d, const Options& opt, Result& R) {
-    R.nodes.clear(); R.refs.clear(); R.roots.assign(d->n_meshes, -1);
-    struct Job { size_t at; Box box; uint32_t first, count; int depth; uint32_t mesh; };
-    std::vector<Job> jobs;
+struct Result {
+    std::vector<MeshTree> trees;       // per mesh (empty nodes = no tree)
+    uint64_t n_nodes = 0, n_refs = 0, leaves = 0, max_leaf = 0;
+};
+
+// Returns an empty string, or an error message.
+inline std::string refine(const qd_scene_desc* d, const Options& opt, Result& R) {
+    R = Result();
+    R.trees.resize(d->n_meshes);
     for (uint32_t mi = 0; mi < d->n_meshes; ++mi) {
         const qd_mesh& m = d->meshes[mi];
         if (m.kd_root < 0) continue;
-        Box root;
-        for (int a = 0; a < 3; ++a) { root.lo[a] = m.bbox_min[a]; root.hi[a] = m.bbox_max[a]; }
-        struct Item { uint32_t src; size_t dst; Box box; int depth; };
-        std::vector<Item> stack;
-        R.roots[mi] = (int32_t)R.nodes.size();
-        R.nodes.push_back(qd_kdnode{0., 3u, 0u});
-        stack.push_back(Item{(uint32_t)m.kd_root, R.nodes.size() - 1, root, 0});
-        while (!stack.empty()) {
-            const Item it = stack.back(); stack.pop_back();
-            const qd_kdnode n = d->kd_nodes[it.src];
-            const uint32_t axis = n.meta & 3u, idx = n.meta >> 2;
-            if (axis == 3u) { jobs.push_back(Job{it.dst, it.box, idx, n.count, it.depth, mi}); continue; }
-            const size_t c = R.nodes.size();
-            R.nodes.push_back(qd_kdnode{0., 3u, 0u});
-            R.nodes.push_back(qd_kdnode{0., 3u, 0u});
-            R.nodes[it.dst] = qd_kdnode{n.split, ((uint32_t)c << 2) | axis, 0u};
-            Box bl = it.box, br = it.box;
-            bl.hi[axis] = n.split; br.lo[axis] = n.split;
-            stack.push_back(Item{idx + 1, c + 1, br, it.depth + 1});
-            stack.push_back(Item{idx, c, bl, it.depth + 1});
-        }
-    }
-    // one subtree per leaf of the caller's tree, built on all host cores
-    std::vector<SubTree> subs(jobs.size());
-    const bool on = opt.max_leaf > 0;
-    unsigned n_thr = std::thread::hardware_concurrency();
-    n_thr = std::max(1u, std::min(n_thr, 16u));
-    if (jobs.size() < 4096) n_thr = 1;
-    std::atomic<size_t> next{0};
-    auto worker = [&]() {
-        for (;;) {
-            const size_t b = next.fetch_add(256), e = std::min(jobs.size(), b + 256);
-            if (b >= jobs.size()) break;
-            for (size_t j = b; j < e; ++j) {
-                const Job& jb = jobs[j];
-                const qd_mesh& m = d->meshes[jb.mesh];
-                if (on) {
-                    Builder bld(d->tri_verts, m.tri_first, opt);
-                    bld.build(subs[j], jb.box, d->leaf_tris + jb.first, jb.count, jb.depth);
-                } else {
-                    subs[j].nodes.assign(1, qd_kdnode{0., 3u, jb.count});
-                    subs[j].refs.assign(d->leaf_tris + jb.first, d->leaf_tris + jb.first + jb.count);
+        MeshTree& T = R.trees[mi];
+        // 1. the caller's inner nodes, copied; one job per leaf
+        struct Job { size_t at; Box box; std::vector<uint32_t> tris; int depth; };
+        std::vector<Job> jobs;
+        {
+            struct Item { uint32_t src; size_t dst; Box box; int depth; };
+            std::vector<Item> stack;
+            Box root;
+            for (int a = 0; a < 3; ++a) { root.lo[a] = m.bbox_min[a]; root.hi[a] = m.bbox_max[a]; }
+            T.nodes.push_back(BNode{0., 0u, 0u, 3});
+            stack.push_back(Item{(uint32_t)m.kd_root, 0, root, 0});
+            while (!stack.empty()) {
+                const Item it = stack.back(); stack.pop_back();
+                const qd_kdnode n = d->kd_nodes[it.src];
+                const uint32_t axis = n.meta & 3u, idx = n.meta >> 2;
+                if (axis == 3u) {
+                    jobs.push_back(Job{it.dst, it.box, std::vector<uint32_t>(d->leaf_tris + idx, d->leaf_tris + idx + n.count), it.depth});
+                    continue;
                 }
+                if (it.depth >= opt.max_depth) return "KD tree deeper than the device traversal stack allows";
+                const size_t c = T.nodes.size();
+                T.nodes.push_back(BNode{0., 0u, 0u, 3});
+                T.nodes.push_back(BNode{0., 0u, 0u, 3});
+                T.nodes[it.dst] = BNode{n.split, (uint32_t)c, 0u, (uint8_t)axis};
+                Box bl = it.box, br = it.box;
+                bl.hi[axis] = n.split; br.lo[axis] = n.split;
+                stack.push_back(Item{idx + 1, c + 1, br, it.depth + 1});
+                stack.push_back(Item{idx, c, bl, it.depth + 1});
             }
         }
-    };
-    if (n_thr == 1) worker();
-    else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < n_thr; ++t) pool.emplace_back(worker);
-        for (auto& t : pool) t.join();
-    }
-    // stitch: subtree node 0 lands in the slot of the leaf it replaces, the rest is appended
-    size_t n_nodes = R.nodes.size(), n_refs = 0;
-    for (const SubTree& s : subs) { n_nodes += s.nodes.size() - 1; n_refs += s.refs.size(); }
-    R.nodes.reserve(n_nodes); R.refs.reserve(n_refs);
-    for (size_t j = 0; j < jobs.size(); ++j) {
-        const SubTree& s = subs[j];
-        const size_t node_base = R.nodes.size() - 1;      // local index i >= 1 -> node_base + i
-        const size_t ref_base = R.refs.size();
-        auto fix = [&](qd_kdnode n) {
-            const uint32_t axis = n.meta & 3u, idx = n.meta >> 2;
-            if (axis == 3u) {
-                n.meta = ((uint32_t)(ref_base + idx) << 2) | 3u;
-                R.leaves++; R.max_leaf = std::max<uint64_t>(R.max_leaf, n.count);
-            } else n.meta = ((uint32_t)(node_base + idx) << 2) | axis;
-            return n;
+        // 2. one subtree per leaf, built on the host cores
+        std::vector<SubTree> subs(jobs.size());
+        unsigned n_thr = std::thread::hardware_concurrency();
+        n_thr = std::max(1u, std::min(n_thr, 16u));
+        if (jobs.size() < 4096) n_thr = 1;
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            Builder bld(d->tri_verts, m.tri_first, opt);
+            for (;;) {
+                const size_t b = next.fetch_add(256), e = std::min(jobs.size(), b + 256);
+                if (b >= jobs.size()) break;
+                for (size_t j = b; j < e; ++j) bld.build(subs[j], jobs[j].box, jobs[j].tris, jobs[j].depth);
+            }
         };
-        R.nodes[jobs[j].at] = fix(s.nodes[0]);
-        for (size_t i = 1; i < s.nodes.size(); ++i) R.nodes.push_back(fix(s.nodes[i]));
-        R.refs.insert(R.refs.end(), s.refs.begin(), s.refs.end());
+        if (n_thr == 1) worker();
+        else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < n_thr; ++t) pool.emplace_back(worker);
+            for (auto& t : pool) t.join();
+        }
+        // stitch: subtree node 0 lands in the slot of the leaf it replaces, the rest is appended
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            const SubTree& s = subs[j];
+            const size_t node_base = T.nodes.size() - 1;      // local index i >= 1 -> node_base + i
+            const size_t ref_base = T.refs.size();
+            auto fix = [&](BNode n) {
+                if (n.axis == 3) {
+                    n.child = (uint32_t)(ref_base + n.child);
+                    R.leaves++; R.max_leaf = std::max<uint64_t>(R.max_leaf, n.count);
+                } else n.child = (uint32_t)(node_base + n.child);
+                return n;
+            };
+            T.nodes[jobs[j].at] = fix(s.nodes[0]);
+            for (size_t i = 1; i < s.nodes.size(); ++i) T.nodes.push_back(fix(s.nodes[i]));
+            T.refs.insert(T.refs.end(), s.refs.begin(), s.refs.end());
+        }
+        R.n_nodes += T.nodes.size(); R.n_refs += T.refs.size();
     }
+    return std::string();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Device records, 32 bytes each, two tree levels per record:
+//   inner record  { double s0, s1, s2; uint32 meta; uint32 0 }   meta = (base >> 2) << 6 | a2 << 4 | a1 << 2 | a0
+//       a0, s0 : axis / plane of the node itself (a0 in 0..2)
+//       a1, s1 : axis / plane of its left child,  a2, s2 : of its right child
+//                axis 3 = that child is a leaf; the 8 bytes of its plane then hold { uint32 first, count }
+//       base   : first of four consecutive records (one 128-byte line) for the grandchildren:
+//                base + 2c + g = child g of inner child c
+//   leaf record   { uint32 first, count; ...; uint32 meta = 3 }  (a grandchild, or a root, that is a leaf)
+// first/count index the leaf reference arrays.  One 32-byte fetch therefore decides two levels of the walk, and a
+// leaf that is the child of a record's node is opened without a fetch of its own.
+struct Record { uint32_t w[8]; };
+
+inline Record leaf_record(uint32_t first, uint32_t count) { return Record{{first, count, 0u, 0u, 0u, 0u, 3u, 0u}}; }
+
+// Appends the records of one mesh tree to `out` (whose size is kept a multiple of 4); leaf references are
+// shifted by ref_base.  Returns the record index of the root.
+inline uint32_t pack(const MeshTree& T, std::vector<Record>& out, size_t ref_base) {
+    auto put_f64 = [](Record& r, int at, double v) { std::memcpy(&r.w[at], &v, 8); };
+    const size_t root = out.size();
+    out.resize(root + 4, leaf_record(0, 0));
+    struct Item { uint32_t node; size_t rec; };
+    std::vector<Item> stack;
+    stack.push_back(Item{0u, root});
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        const BNode& n = T.nodes[it.node];
+        if (n.axis == 3) { out[it.rec] = leaf_record((uint32_t)(ref_base + n.child), n.count); continue; }
+        Record r{};
+        put_f64(r, 0, n.split);
+        uint32_t meta = n.axis;
+        size_t base = 0;
+        const bool any_inner = T.nodes[n.child].axis != 3 || T.nodes[n.child + 1].axis != 3;
+        if (any_inner) { base = out.size(); out.resize(base + 4, leaf_record(0, 0)); }
+        meta |= (uint32_t)((base >> 2) << 6);
+        for (uint32_t c = 0; c < 2; ++c) {
+            const BNode& ch = T.nodes[n.child + c];
+            meta |= (uint32_t)ch.axis << (2 + 2 * c);
+            if (ch.axis == 3) { r.w[2 + 2 * c] = (uint32_t)(ref_base + ch.child); r.w[3 + 2 * c] = ch.count; continue; }
+            put_f64(r, 2 + 2 * c, ch.split);
+            stack.push_back(Item{ch.child + 1, base + 2 * c + 1});
+            stack.push_back(Item{ch.child, base + 2 * c});
+        }
+        r.w[6] = meta;
+        out[it.rec] = r;
+    }
+    return (uint32_t)root;
 }
 
 }  // namespace qd_refine

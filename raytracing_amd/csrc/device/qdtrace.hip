@@ -529,54 +529,6 @@ struct qd_scene {
 
 namespace {
 
-// KD nodes re-ordered for the device: a node's two children and their four children share one 128-byte
-// block (8 slots of 16 bytes, 6 used): slots 0/1 = the children, slots 2+2s/3+2s = the children of slot s.
-// mesh_intersect relies on this to fetch a slot-0/1 node together with its children in one round trip.
-// Child adjacency (index, index + 1) is kept.  Leaf references become global triangle indices.
-void relayout_kd(const qd_refine::Result& R, std::vector<qd_kdnode>& out, std::vector<qd_mesh>& meshes, std::vector<uint32_t>& leaf_global) {
-    const qd_kdnode* src = R.nodes.data();
-    leaf_global = R.refs;
-    const qd_kdnode empty{0., 3u, 0u};   // unused slot = empty leaf
-    struct Item { uint32_t src_pair; size_t dst_parent; };
-    std::vector<Item> stack;
-    for (size_t mi = 0; mi < meshes.size(); ++mi) {
-        qd_mesh& m = meshes[mi];
-        if (m.kd_root < 0) continue;
-        auto mark_leaf = [&](const qd_kdnode& n) {
-            const size_t first = n.meta >> 2;
-            for (size_t r = first; r < first + n.count; ++r) leaf_global[r] = R.refs[r] + m.tri_first;
-        };
-        const size_t rb = out.size() + 7;    // the root sits alone in the last slot of a block: slots 0/1 promise children in slots 2..5
-        out.resize(rb + 1, empty);
-        out[rb] = src[R.roots[mi]];
-        m.kd_root = (int32_t)rb;
-        if ((out[rb].meta & 3u) == 3u) { mark_leaf(out[rb]); continue; }
-        stack.push_back(Item{out[rb].meta >> 2, rb});
-        while (!stack.empty()) {
-            const Item it = stack.back(); stack.pop_back();
-            const size_t base = out.size();
-            out.resize(base + 8, empty);
-            out[it.dst_parent].meta = ((uint32_t)base << 2) | (out[it.dst_parent].meta & 3u);
-            Item pending[4]; int np = 0;
-            for (int k = 0; k < 2; ++k) {
-                const qd_kdnode n = src[it.src_pair + k];
-                out[base + k] = n;
-                if ((n.meta & 3u) == 3u) { mark_leaf(n); continue; }
-                const uint32_t gc = n.meta >> 2;
-                const size_t gslot = base + 2 + 2 * k;
-                out[base + k].meta = ((uint32_t)gslot << 2) | (n.meta & 3u);
-                for (int j = 0; j < 2; ++j) {
-                    const qd_kdnode g = src[gc + j];
-                    out[gslot + j] = g;
-                    if ((g.meta & 3u) == 3u) mark_leaf(g);
-                    else pending[np++] = Item{g.meta >> 2, gslot + (size_t)j};
-                }
-            }
-            for (int q = np - 1; q >= 0; --q) stack.push_back(pending[q]);   // depth-first, left subtree next
-        }
-    }
-}
-
 template <class T>
 int upload(qd_scene* s, const T* src, size_t n, const T** dst) {
     *dst = nullptr;
@@ -750,21 +702,28 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     int rc = 0;
     rc |= upload(s, desc->nodes, desc->n_nodes, &d.nodes);
     rc |= upload(s, desc->geoms, desc->n_geoms, &d.geoms);
-    std::vector<qd_kdnode> kd_blocked;
+    std::vector<qd_refine::Record> kd_records;
     std::vector<qd_mesh> meshes_dev(desc->meshes, desc->meshes + desc->n_meshes);
-    std::vector<uint32_t> leaf_global;
+    std::vector<uint32_t> leaf_global;       // leaf references as GLOBAL triangle indices
     {
         qd_refine::Options opt;
         opt.max_leaf = g_refine_leaf;
         opt.cost_step = g_refine_cost;
         opt.max_depth = kKdStack - 2;
         qd_refine::Result refined;
-        qd_refine::refine(desc, opt, refined);
-        if (refined.refs.size() >= (1u << 30) || refined.nodes.size() >= (1u << 29)) { delete s; return set_err("qd_scene_create: KD tree too large for 30-bit indices"); }
-        relayout_kd(refined, kd_blocked, meshes_dev, leaf_global);
-        s->kd_nodes = refined.nodes.size(); s->kd_refs = refined.refs.size(); s->kd_leaves = refined.leaves; s->kd_max_leaf = refined.max_leaf;
+        const std::string err = qd_refine::refine(desc, opt, refined);
+        if (!err.empty()) { delete s; return set_err("qd_scene_create: " + err); }
+        if (refined.n_refs >= (1ull << 32) || refined.n_nodes >= (1ull << 27)) { delete s; return set_err("qd_scene_create: KD tree too large for the 28-bit record index"); }
+        leaf_global.reserve(refined.n_refs);
+        for (size_t mi = 0; mi < meshes_dev.size(); ++mi) {
+            const qd_refine::MeshTree& T = refined.trees[mi];
+            if (T.nodes.empty()) continue;
+            meshes_dev[mi].kd_root = (int32_t)qd_refine::pack(T, kd_records, leaf_global.size());
+            for (uint32_t t : T.refs) leaf_global.push_back(t + meshes_dev[mi].tri_first);
+        }
+        s->kd_nodes = refined.n_nodes; s->kd_refs = refined.n_refs; s->kd_leaves = refined.leaves; s->kd_max_leaf = refined.max_leaf;
     }
-    if (kd_blocked.size() >= (1u << 30)) { delete s; return set_err("qd_scene_create: KD tree too large for 30-bit node indices"); }
+    if (kd_records.size() >= (1u << 28)) { delete s; return set_err("qd_scene_create: KD tree too large for the 28-bit record index"); }
     rc |= upload(s, meshes_dev.data(), meshes_dev.size(), &d.meshes);
     rc |= upload(s, desc->hfields, desc->n_hfields, &d.hfields);
     rc |= upload(s, desc->shaders, desc->n_shaders, &d.shaders);
@@ -776,7 +735,7 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     rc |= upload(s, desc->tri_verts, (size_t)desc->n_tris * 9, &d.tri_verts);
     rc |= upload(s, desc->tri_gnormal, (size_t)desc->n_tris * 3, &d.tri_gnormal);
     rc |= upload(s, desc->tri_shade, (size_t)desc->n_tris * 21, &d.tri_shade);
-    rc |= upload(s, kd_blocked.data(), kd_blocked.size(), &d.kd_nodes);
+    { const qd_refine::Record* recs = nullptr; rc |= upload(s, kd_records.data(), kd_records.size(), &recs); d.kd_nodes = (const qd_kdnode*)recs; }
     rc |= upload(s, leaf_global.data(), leaf_global.size(), &d.leaf_tris);
     if (!rc) {
         const size_t n_words = leaf_global.size() * 9;
