@@ -244,6 +244,18 @@ int qd_render(qd_scene* scene, const qd_camera* camera, const qd_settings* setti
               int32_t* hit_node, int32_t* hit_tri, double* hit_dist,
               qd_stats* stats);
 
+/* Replaces: the anti-aliasing pass of RenderScene (src/main.cpp:106-153, IsTooDifferent :58-83), which
+ * the reference runs after SimpleRender when settings.wantAA is set.
+ *   rgb : caller-owned HOST buffer holding the finished first pass of the WHOLE frame (what qd_render wrote
+ *         for 0,0,W,H), pixel (x,y) at rgb[y*row_pitch_floats + x*3]; replaced in place by the anti-aliased frame.
+ * Semantics kept: 48x48 buckets in display order, a bucket's pixels are marked before any of them is
+ * replaced, marked pixels become (first + 4 more rays at the fixed offsets) / 5, pixels of earlier buckets
+ * are seen already replaced, neighbours outside the frame read as black and coordinates >= 1920 are skipped
+ * (the static vfb), showAA paints aaDebugColor, wantAdaptiveAA false marks everything.
+ * The caller decides whether to call it (settings.wantAA); the function itself does not look at want_aa. */
+int qd_antialias(qd_scene* scene, const qd_camera* camera, const qd_settings* settings,
+                 float* rgb, size_t row_pitch_floats, qd_stats* stats);
+
 /* Same as qd_render but every output pointer is DEVICE memory and the call only
  * enqueues work on `hip_stream` (a hipStream_t passed as void*; NULL = default
  * stream).  Pixels are selected by tile ownership instead of a rectangle:

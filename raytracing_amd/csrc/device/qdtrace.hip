@@ -37,7 +37,9 @@ struct Params {
     int W, H;
     float ambient[3];
     uint32_t max_depth;
-    int mode;                     // 0 = rectangle, 1 = interleaved tiles (compacted output)
+    int mode;                     // 0 = rectangle, 1 = interleaved tiles (compacted output), 2 = anti-aliasing taps of listed pixels
+    const uint32_t* aa_pixels;    // mode 2: x | y << 16 per listed pixel; sample j = tap 1 + j % 4 of pixel j / 4
+    uint32_t n_samples;           // mode 2: 4 * listed pixels
     int x0, y0, rw, rh;           // rectangle
     int tile, tiles_x, phase, stride;
     uint32_t n_units;             // 8x8 pixel units to render
@@ -313,12 +315,20 @@ QD_DEV uint32_t wave_sum(uint32_t v) {
 #endif
 constexpr uint32_t kWavesPerCU = 4 * QD_WAVES_PER_EU;
 
-struct PixelSlot { int x, y; uint32_t out_idx; bool valid; };
+struct PixelSlot { int x, y; uint32_t out_idx; bool valid; uint32_t tap; };
 
 QD_DEV PixelSlot map_pixel(const Params& P, uint32_t unit, uint32_t p) {
     PixelSlot s;
+    s.tap = 0;
     const int lx8 = p & 7, ly8 = p >> 3;
-    if (P.mode == 0) {
+    if (P.mode == 2) {
+        const uint32_t j = unit * 64u + p;
+        s.valid = j < P.n_samples;
+        const uint32_t xy = s.valid ? P.aa_pixels[j >> 2] : 0u;
+        s.x = (int)(xy & 0xffffu); s.y = (int)(xy >> 16);
+        s.tap = 1u + (j & 3u);
+        s.out_idx = j;
+    } else if (P.mode == 0) {
         const int ux = unit % P.units_x, uy = unit / P.units_x;
         const int px = ux * 8 + lx8, py = uy * 8 + ly8;
         s.x = P.x0 + px; s.y = P.y0 + py;
@@ -380,12 +390,15 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
                 if (px.valid) {
                     // Camera::GetScreenRay, src/camera.cpp:26-41 (integer pixel coordinates, no +0.5)
                     const DV TL = ld3(P.cam.top_left), TR = ld3(P.cam.top_right), BL = ld3(P.cam.bottom_left), pos = ld3(P.cam.position);
-                    const DV through = TL + (TR - TL) * ((double)px.x / P.W) + (BL - TL) * ((double)px.y / P.H);
+                    // anti-aliasing taps: kernel offsets of src/main.cpp:108-114
+                    const double kx = (px.tap == 1u || px.tap == 4u) ? 0.6 : (px.tap == 3u ? 0.3 : 0.0);
+                    const double ky = (px.tap == 2u || px.tap == 4u) ? 0.6 : (px.tap == 3u ? 0.3 : 0.0);
+                    const DV through = TL + (TR - TL) * (((double)px.x + kx) / P.W) + (BL - TL) * (((double)px.y + ky) / P.H);
                     Task t;
                     t.o = pos; t.d = normalize(through - pos);
                     t.w = mkc(1.f, 1.f, 1.f);
                     t.flags_depth = kFlagPrimary;
-                    t.path = pixel_path(px.x, px.y, 0);
+                    t.path = pixel_path(px.x, px.y, px.tap);
                     t.aux0 = t.aux1 = 0;
                     q.push(t);
                     ++n_primary;
@@ -499,6 +512,96 @@ __global__ void quantize_kernel(const float* __restrict__ rgb, uint8_t* __restri
     uint8_t* o = out + (size_t)(H - 1 - y) * row_bytes + (size_t)x * 3;
     auto q8 = [](float v) { const double c = fmin(fmax((double)v, 0.0), 1.0); return (uint8_t)(int)floor(c * 255.0 + 0.5); };
     o[0] = q8(p[2]); o[1] = q8(p[1]); o[2] = q8(p[0]);
+}
+
+
+// ------------------------------------------------------------------------------------------ anti-aliasing pass
+// RenderScene's second pass (src/main.cpp:106-153) and IsTooDifferent (:58-83).  The reference walks the
+// buckets in display order; for each bucket it first marks the pixels that differ from a neighbour, then replaces
+// every marked pixel by the average of its first-pass colour and four more rays, IN PLACE.  A pixel on a bucket
+// border therefore sees neighbours in earlier buckets already anti-aliased.  Here:
+//   aa_mark_kernel    : marks with first-pass colours only, and lists every pixel that is marked or that has a
+//                       neighbour in an earlier bucket (only those can still become marked) -> taps are traced
+//   aa_combine_kernel : ((((first + t1) + t2) + t3) + t4) / 5 in the reference's order of float additions
+//   aa_resolve_kernel : the mark / replace rule with "earlier bucket -> current value, else first-pass value";
+//                       iterated to its fixed point, which is the sequential result because the dependency
+//                       (earlier buckets only) has no cycles.
+QD_DEV int aa_bucket_order(int x, int y, int W) {          // GetBucketList, src/sdl.cpp:253-276: 48 x 48, serpentine rows
+    const int bw = (W - 1) / 48 + 1, bx = x / 48, by = y / 48;
+    return by * bw + ((by & 1) ? bw - 1 - bx : bx);
+}
+constexpr int kVfb = 1920;                                  // VFB_MAX_SIZE: neighbours beyond it are skipped, inside it but
+                                                            // outside the frame they read as black (static vfb, src/main.cpp:15)
+// cur == nullptr: every neighbour is read from `first`
+QD_DEV bool aa_too_different(const float* first, const float* cur, int x, int y, int W, int H, double threshold) {
+    const int dx[8] = {0, 0, -1, 1, -1, -1, 1, 1}, dy[8] = {1, -1, 0, 0, -1, 1, 1, -1};
+    const float* mine = first + ((size_t)y * W + x) * 3;
+    const int my_order = aa_bucket_order(x, y, W);
+    bool out = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned nx = (unsigned)x + dx[i], ny = (unsigned)y + dy[i];
+        if ((unsigned)kVfb <= nx || (unsigned)kVfb <= ny) continue;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        if ((int)nx < W && (int)ny < H) {
+            const bool earlier = cur && aa_bucket_order((int)nx, (int)ny, W) < my_order;
+            const float* q = (earlier ? cur : first) + ((size_t)ny * W + nx) * 3;
+            o0 = q[0]; o1 = q[1]; o2 = q[2];
+        }
+        double diff = 0;
+        diff += fabsf(mine[0] - o0); diff += fabsf(mine[1] - o1); diff += fabsf(mine[2] - o2);
+        if (diff > threshold) out = true;
+    }
+    return out;
+}
+
+__global__ void aa_mark_kernel(const float* __restrict__ first, int W, int H, int adaptive, double threshold,
+                               int32_t* __restrict__ slot, uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    bool cand = !adaptive || aa_too_different(first, nullptr, x, y, W, H, threshold);
+    if (!cand) {
+        const int my_order = aa_bucket_order(x, y, W);
+        for (int dy = -1; dy <= 1 && !cand; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int nx = x + dx, ny = y + dy;
+                if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
+                if (aa_bucket_order(nx, ny, W) < my_order) { cand = true; break; }
+            }
+    }
+    int32_t sl = -1;
+    if (cand) { sl = (int32_t)atomicAdd(count, 1u); list[sl] = (uint32_t)x | ((uint32_t)y << 16); }
+    slot[(size_t)y * W + x] = sl;
+}
+
+__global__ void aa_combine_kernel(const float* __restrict__ first, const float* __restrict__ taps, const uint32_t* __restrict__ list,
+                                  uint32_t n, int W, float* __restrict__ aa) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t xy = list[j];
+    const float* f = first + ((size_t)(xy >> 16) * W + (xy & 0xffffu)) * 3;
+    Col r = mkc(f[0], f[1], f[2]);
+    for (int t = 0; t < 4; ++t) { const float* q = taps + ((size_t)j * 4 + t) * 3; r = r + mkc(q[0], q[1], q[2]); }
+    r = r / (float)double(5);
+    aa[(size_t)j * 3] = r.r; aa[(size_t)j * 3 + 1] = r.g; aa[(size_t)j * 3 + 2] = r.b;
+}
+
+__global__ void aa_resolve_kernel(const float* __restrict__ first, const float* __restrict__ cur, float* __restrict__ next,
+                                  const float* __restrict__ aa, const int32_t* __restrict__ slot, int W, int H, int adaptive, double threshold,
+                                  int show, float dbg_r, float dbg_g, float dbg_b, int* __restrict__ changed, int* __restrict__ error_flag) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    const size_t i = ((size_t)y * W + x) * 3;
+    const bool need = !adaptive || aa_too_different(first, cur, x, y, W, H, threshold);
+    float r = first[i], g = first[i + 1], b = first[i + 2];
+    if (need) {
+        const int32_t sl = slot[(size_t)y * W + x];
+        if (show) { r = dbg_r; g = dbg_g; b = dbg_b; }
+        else if (sl < 0) *error_flag = 2;                   // cannot happen: the listed set covers every pixel that can be marked
+        else { r = aa[(size_t)sl * 3]; g = aa[(size_t)sl * 3 + 1]; b = aa[(size_t)sl * 3 + 2]; }
+    }
+    if (r != cur[i] || g != cur[i + 1] || b != cur[i + 2]) *changed = 1;
+    next[i] = r; next[i + 1] = g; next[i + 2] = b;
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -832,6 +935,86 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
 #ifdef QD_PROFILE
         fprintf(stderr, "[qd profile] wave-cycles total %llu sched %llu trace %llu shade %llu | kd lane-iters %llu wave-iters %llu | xform %llu mesh %llu analytic %llu bookkeeping %llu\n", h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[7], h[6]);
 #endif
+        stats->rays = h[0]; stats->primary_rays = h[1]; stats->shadow_rays = h[2]; stats->depth_killed = h[3];
+        stats->kd_nodes_visited = h[4]; stats->tris_tested = h[5]; stats->mesh_queries = h[6];
+        stats->kernel_ms = ms;
+    }
+    cleanup();
+#undef TRY2
+    return 0;
+}
+
+
+extern "C" int qd_antialias(qd_scene* s, const qd_camera* cam, const qd_settings* st, float* rgb, size_t pitch, qd_stats* stats) {
+    if (!s || !cam || !st || !rgb) return set_err("qd_antialias: null argument");
+    const int W = st->frame_width, H = st->frame_height;
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return set_err("qd_antialias: frame size out of range");
+    if (pitch < (size_t)W * 3) return set_err("qd_antialias: row pitch smaller than the frame");
+    if (ensure_stack(s, st->max_trace_depth)) return -1;
+    const size_t npx = (size_t)W * H;
+    float *d_first = nullptr, *d_a = nullptr, *d_b = nullptr, *d_taps = nullptr, *d_aa = nullptr;
+    int32_t* d_slot = nullptr; uint32_t* d_list = nullptr; uint32_t* d_count = nullptr; int* d_changed = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {(void*)d_first, (void*)d_a, (void*)d_b, (void*)d_taps, (void*)d_aa, (void*)d_slot, (void*)d_list, (void*)d_count, (void*)d_changed})
+            if (p) (void)hipFree(p);
+        if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
+    };
+#define TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return -1; } } while (0)
+    TRY2(hipMalloc((void**)&d_first, npx * 3 * sizeof(float)));
+    TRY2(hipMalloc((void**)&d_a, npx * 3 * sizeof(float)));
+    TRY2(hipMalloc((void**)&d_b, npx * 3 * sizeof(float)));
+    TRY2(hipMalloc((void**)&d_slot, npx * sizeof(int32_t)));
+    TRY2(hipMalloc((void**)&d_list, npx * sizeof(uint32_t)));
+    TRY2(hipMalloc((void**)&d_count, sizeof(uint32_t)));
+    TRY2(hipMalloc((void**)&d_changed, sizeof(int)));
+    TRY2(hipMemcpy2D(d_first, (size_t)W * 3 * sizeof(float), rgb, pitch * sizeof(float), (size_t)W * 3 * sizeof(float), H, hipMemcpyHostToDevice));
+    TRY2(hipMemset(d_count, 0, sizeof(uint32_t)));
+    TRY2(hipMemsetAsync(s->stats, 0, 16 * sizeof(unsigned long long), nullptr));
+    TRY2(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
+    const dim3 blk(64), grd((unsigned)(W + 63) / 64, (unsigned)H);
+    hipLaunchKernelGGL(aa_mark_kernel, grd, blk, 0, nullptr, d_first, W, H, st->want_adaptive_aa, st->aa_threshold, d_slot, d_list, d_count);
+    uint32_t n_list = 0;
+    TRY2(hipMemcpy(&n_list, d_count, sizeof n_list, hipMemcpyDeviceToHost));
+    float ms = 0;
+    if (n_list && !st->show_aa) {
+        TRY2(hipMalloc((void**)&d_taps, (size_t)n_list * 4 * 3 * sizeof(float)));
+        TRY2(hipMalloc((void**)&d_aa, (size_t)n_list * 3 * sizeof(float)));
+        Params P; fill_common(P, cam, st);
+        P.mode = 2; P.aa_pixels = d_list; P.n_samples = n_list * 4u;
+        P.n_units = (P.n_samples + 63u) / 64u;
+        P.rgb = d_taps; P.stats = s->stats;
+        TRY2(hipEventCreate(&e0)); TRY2(hipEventCreate(&e1));
+        TRY2(hipEventRecord(e0, nullptr));
+        if (launch(s, P, nullptr)) { cleanup(); return -1; }
+        TRY2(hipEventRecord(e1, nullptr));
+        hipLaunchKernelGGL(aa_combine_kernel, dim3((n_list + 255u) / 256u), dim3(256), 0, nullptr, d_first, d_taps, d_list, n_list, W, d_aa);
+        TRY2(hipEventSynchronize(e1));
+        TRY2(hipEventElapsedTime(&ms, e0, e1));
+    }
+    // fixed point of the bucket-ordered rule; iteration k is exact for every pixel whose chain of earlier-bucket
+    // neighbours is shorter than k, so the bucket count bounds the loop
+    TRY2(hipMemcpy(d_a, d_first, npx * 3 * sizeof(float), hipMemcpyDeviceToDevice));
+    float *cur = d_a, *next = d_b;
+    const int max_iter = ((W - 1) / 48 + 1) * ((H - 1) / 48 + 1) + 2;
+    int iter = 0;
+    for (;; ++iter) {
+        if (iter > max_iter) { cleanup(); return set_err("qd_antialias: mark / replace rule did not settle"); }
+        TRY2(hipMemset(d_changed, 0, sizeof(int)));
+        hipLaunchKernelGGL(aa_resolve_kernel, grd, blk, 0, nullptr, d_first, cur, next, d_aa, d_slot, W, H, st->want_adaptive_aa, st->aa_threshold,
+                           st->show_aa, st->aa_debug_color[0], st->aa_debug_color[1], st->aa_debug_color[2], d_changed, s->error_flag);
+        int changed = 0;
+        TRY2(hipMemcpy(&changed, d_changed, sizeof changed, hipMemcpyDeviceToHost));
+        std::swap(cur, next);
+        if (!changed) break;
+    }
+    int err_flag = 0;
+    TRY2(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (err_flag) { cleanup(); return set_err(err_flag == 2 ? "qd_antialias: marked pixel outside the traced set" : "qd_antialias: ray queue overflow on device"); }
+    TRY2(hipMemcpy2D(rgb, pitch * sizeof(float), cur, (size_t)W * 3 * sizeof(float), (size_t)W * 3 * sizeof(float), H, hipMemcpyDeviceToHost));
+    if (stats) {
+        unsigned long long h[16];
+        TRY2(hipMemcpy(h, s->stats, sizeof h, hipMemcpyDeviceToHost));
         stats->rays = h[0]; stats->primary_rays = h[1]; stats->shadow_rays = h[2]; stats->depth_killed = h[3];
         stats->kd_nodes_visited = h[4]; stats->tris_tested = h[5]; stats->mesh_queries = h[6];
         stats->kernel_ms = ms;

@@ -31,6 +31,7 @@ def lib():
         L.qd_scene_check.argtypes = [C.c_void_p]
         L.qd_render.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, P(abi.QdStats)]
+        L.qd_antialias.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_void_p, C.c_size_t, P(abi.QdStats)]
         L.qd_render_tiles_async.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p]
         L.qd_untile_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -90,6 +91,26 @@ class DeviceScene:
                                hn.ctypes.data if hits else None, ht.ctypes.data if hits else None,
                                hd.ctypes.data if hits else None, C.byref(stats)), "qd_render")
         return rgb, ((hn, ht, hd) if hits else None), stats.as_dict()
+
+    def antialias(self, rgb, camera=None, settings=None):
+        """RenderScene's AA pass on a finished first-pass frame (float32[H, W, 3], C-contiguous); in place."""
+        st = settings if settings is not None else self.host_scene.settings
+        cam = camera if camera is not None else self.host_scene.camera
+        if rgb.dtype != np.float32 or not rgb.flags["C_CONTIGUOUS"] or rgb.shape != (st.frame_height, st.frame_width, 3):
+            raise DeviceError("antialias: rgb must be C-contiguous float32[frame_height, frame_width, 3]")
+        stats = abi.QdStats()
+        _check(lib().qd_antialias(self._h, C.byref(cam), C.byref(st), rgb.ctypes.data, st.frame_width * 3, C.byref(stats)), "qd_antialias")
+        return stats.as_dict()
+
+    def render_frame(self, camera=None, settings=None):
+        """RenderScene (src/main.cpp:106-161): first pass, then the AA pass when settings.wantAA is set."""
+        st = settings if settings is not None else self.host_scene.settings
+        rgb, _, stats = self.render(camera=camera, settings=settings)
+        if st.want_aa:
+            aa = self.antialias(rgb, camera=camera, settings=settings)
+            for k in ("rays", "primary_rays", "shadow_rays", "depth_killed", "kd_nodes_visited", "tris_tested", "mesh_queries", "kernel_ms"):
+                stats[k] += aa[k]
+        return rgb, stats
 
     def render_tiles_async(self, rgb_dev_ptr, tile, phase, stride, stats_dev_ptr=None, stream=None,
                            camera=None, settings=None):
