@@ -63,6 +63,10 @@ struct Counters {
 #endif
 
 constexpr int kKdStack = 72;
+#ifndef QD_LDS_STACK
+#define QD_LDS_STACK 8
+#endif
+constexpr int kLdsStack = QD_LDS_STACK;     // stack levels kept in LDS: 8 x 64 lanes x 8 bytes = 4 KB per wave
 #ifndef QD_TRI_BATCH
 #define QD_TRI_BATCH 16
 #endif
@@ -205,8 +209,22 @@ __device__ __attribute__((noinline)) MHit mesh_query(MeshData D, int mesh_idx, D
         // issue their loads before anybody waits, so lanes at different stages of their walk share every trip
         // instead of waiting for each other at leaf boundaries.  The top of the far-child stack is kept in
         // registers: a pop re-fills it from scratch without anything waiting on that load.
-        uint32_t stk_node[kKdStack];
-        double stk_t[kKdStack];
+        // Far-child stack: the top entry in registers, the next kLdsStack entries in LDS (8 bytes each: token and the
+        // interval end rounded UP to float, which only widens the interval), deeper ones in scratch.  The workgroup
+        // is one wave, so the LDS block belongs to this wave alone.
+        __shared__ uint2 lds_stack[kLdsStack][64];
+        uint2 stk_deep[kKdStack - kLdsStack];
+        const uint32_t lane_id = threadIdx.x & 63u;
+        auto stack_put = [&](int at, uint32_t tok, double t) {
+            float f = (float)t;
+            if ((double)f < t) f = __uint_as_float(__float_as_uint(f) + (f >= 0.f ? 1u : 0xffffffffu));   // next float up
+            const uint2 e = make_uint2(tok, __float_as_uint(f));
+            if (at < kLdsStack) lds_stack[at][lane_id] = e; else stk_deep[at - kLdsStack] = e;
+        };
+        auto stack_get = [&](int at, uint32_t& tok, double& t) {
+            const uint2 e = at < kLdsStack ? lds_stack[at][lane_id] : stk_deep[at - kLdsStack];
+            tok = e.x; t = (double)__uint_as_float(e.y);
+        };
         int sp = 0;                                   // entries in use; entry sp-1 lives in top_*, the rest in stk_*[0 .. sp-2]
         uint32_t top_node = 0;
         double top_t = 0.;
@@ -237,7 +255,7 @@ __device__ __attribute__((noinline)) MHit mesh_query(MeshData D, int mesh_idx, D
             if (t < tmin - slack) return near_s ^ 1u;               // crossed before the interval starts
             // (also reached when t is NaN: ray inside the plane)
             if (sp <= kKdStack) {
-                if (sp > 0) { stk_node[sp - 1] = top_node; stk_t[sp - 1] = top_t; }
+                if (sp > 0) stack_put(sp - 1, top_node, top_t);
                 top_node = near_s ? tok_left : tok_right; top_t = tmax; ++sp;
             }
             tmax = (t == t) ? fmin(tmax, t + slack) : tmax;
@@ -300,7 +318,7 @@ __device__ __attribute__((noinline)) MHit mesh_query(MeshData D, int mesh_idx, D
                 else {
                     node = top_node; tmin = tmax; tmax = top_t;
                     --sp;
-                    if (sp > 0) { top_node = stk_node[sp - 1]; top_t = stk_t[sp - 1]; }
+                    if (sp > 0) stack_get(sp - 1, top_node, top_t);
                 }
             }
         }

@@ -163,6 +163,14 @@ def test_nested_layered_and_csg_are_rejected_loudly(tmp_path):
 
 
 # ---------------------------------------------------------------- anti-aliasing pass (src/main.cpp:58-83, 106-153)
+def _aa_settings(s, **kw):
+    """load_scene caches scene objects across tests: set every AA field explicitly, hand back the old values."""
+    old = {k: getattr(s.settings, k) for k in ("want_aa", "want_adaptive_aa", "show_aa", "aa_threshold")}
+    for k, v in kw.items():
+        setattr(s.settings, k, v)
+    return old
+
+
 def _aa_compare(s):
     ds = device.DeviceScene(s)
     try:
@@ -176,8 +184,11 @@ def _aa_compare(s):
 
 def test_adaptive_aa_frame_matches_oracle(load_scene):
     s = load_scene("hw9/nonconvex.qdmg")          # the reference scene that ships with wantAA on
-    assert s.settings.want_aa == 1
-    rgb, orgb, err, st, ost = _aa_compare(s)
+    old = _aa_settings(s, want_aa=1, want_adaptive_aa=1, show_aa=0)
+    try:
+        rgb, orgb, err, st, ost = _aa_compare(s)
+    finally:
+        _aa_settings(s, **old)
     n = err.size
     assert int((~(err <= COLOUR_TOL)).sum()) <= max(1, int(n * NEAR_TIE_BUDGET)), float(np.nanmax(err))
     assert st["primary_rays"] > n                 # the second pass really traced extra camera rays
@@ -185,8 +196,11 @@ def test_adaptive_aa_frame_matches_oracle(load_scene):
 
 def test_aa_mask_is_the_reference_mask(load_scene):
     s = load_scene("hw9/nonconvex.qdmg")
-    s.settings.show_aa = 1                        # marked pixels are painted with aaDebugColor: compares the mask itself
-    rgb, orgb, err, _, _ = _aa_compare(s)
+    old = _aa_settings(s, want_aa=1, want_adaptive_aa=1, show_aa=1)   # marked pixels are painted with aaDebugColor: compares the mask itself
+    try:
+        rgb, orgb, err, _, _ = _aa_compare(s)
+    finally:
+        _aa_settings(s, **old)
     dbg = np.array(list(s.settings.aa_debug_color), np.float32)
     mask_gpu = (rgb == dbg).all(axis=2)
     mask_cpu = (orgb == dbg).all(axis=2)
@@ -196,13 +210,14 @@ def test_aa_mask_is_the_reference_mask(load_scene):
 
 def test_full_aa_and_bucket_border_dependency(load_scene):
     s = load_scene("window_fixed.qdmg")
-    s.settings.want_aa = 1
-    s.settings.want_adaptive_aa = 1
-    s.settings.aa_threshold = 0.02               # low threshold: long chains of marked pixels across bucket borders
-    rgb, orgb, err, st, ost = _aa_compare(s)
-    n = err.size
-    assert int((~(err <= COLOUR_TOL)).sum()) <= max(1, int(n * NEAR_TIE_BUDGET)), float(np.nanmax(err))
-    s.settings.want_adaptive_aa = 0              # every pixel gets its four extra rays
-    rgb, orgb, err, st, ost = _aa_compare(s)
-    assert int((~(err <= COLOUR_TOL)).sum()) <= max(1, int(n * NEAR_TIE_BUDGET)), float(np.nanmax(err))
-    assert st["primary_rays"] == 5 * n
+    old = _aa_settings(s, want_aa=1, want_adaptive_aa=1, show_aa=0, aa_threshold=0.02)   # low threshold: long chains of marked pixels across bucket borders
+    try:
+        rgb, orgb, err, st, ost = _aa_compare(s)
+        n = err.size
+        assert int((~(err <= COLOUR_TOL)).sum()) <= max(1, int(n * NEAR_TIE_BUDGET)), float(np.nanmax(err))
+        s.settings.want_adaptive_aa = 0              # every pixel gets its four extra rays
+        rgb, orgb, err, st, ost = _aa_compare(s)
+        assert int((~(err <= COLOUR_TOL)).sum()) <= max(1, int(n * NEAR_TIE_BUDGET)), float(np.nanmax(err))
+        assert st["primary_rays"] == 5 * n
+    finally:
+        _aa_settings(s, **old)
