@@ -67,10 +67,6 @@ constexpr int kKdStack = 72;
 #define QD_LDS_STACK 8
 #endif
 constexpr int kLdsStack = QD_LDS_STACK;     // stack levels kept in LDS: 8 x 64 lanes x 8 bytes = 4 KB per wave
-#ifndef QD_TRI_BATCH
-#define QD_TRI_BATCH 16
-#endif
-constexpr int kTriBatch = QD_TRI_BATCH;   // lanes waiting inside a leaf before the wave runs a triangle pass
 
 // KD node as one 16-byte load (hipMalloc'd arrays are 256-byte aligned, nodes are 16 bytes)
 struct KdNode { double split; uint32_t meta, count; };
@@ -239,6 +235,7 @@ __device__ __attribute__((noinline)) MHit mesh_query(MeshData D, int mesh_idx, D
         const gp_f64 leaf_verts = (gp_f64)D.leaf_verts;
         const gp_u32 leaf_tris = (gp_u32)D.leaf_tris;
         TriV tr;
+        tr.A = tr.AB = tr.AC = mk(0., 0., 0.);
         bool alive = true;
         bool leaf_done = false;
         // One split plane: returns the side (0 left, 1 right) to continue in and queues the other side's token when
@@ -261,36 +258,37 @@ __device__ __attribute__((noinline)) MHit mesh_query(MeshData D, int mesh_idx, D
             tmax = (t == t) ? fmin(tmax, t + slack) : tmax;
             return near_s;
         };
-        // Every pass of the loop is either a node pass or a triangle pass for the whole wave (a uniform branch, so
-        // the other kind's instructions are not issued at all).  Lanes that have opened a leaf wait until
-        // kTriBatch lanes are in that state, or nobody is left walking nodes.
+        // One loop, one trip to memory per iteration.  A lane is either at a record (fetch 32 bytes, step down two
+        // levels or open a leaf) or inside a leaf (fetch one triangle, test it); both kinds of lanes issue their loads
+        // before anybody waits, so lanes at different stages of their walk share every trip.
         for (;;) {
             const unsigned long long m_alive = __ballot(alive);
             if (!m_alive) break;
             const bool in_leaf = alive && left != 0u;
-            const int n_leaf = __popcll(__ballot(in_leaf)), n_node = __popcll(m_alive) - n_leaf;
-            const bool tri_pass = n_leaf >= kTriBatch || n_node == 0;
 #ifdef QD_PROFILE
             {   // diagnostic: lane iterations in n_nodes, wave iterations in n_tris (credited to the first live lane)
-                if (alive && (in_leaf == tri_pass)) n_nodes++;
+                if (alive) n_nodes++;
                 if (alive && (unsigned)(__ffsll((long long)m_alive) - 1) == (threadIdx.x & 63u)) n_tris++;
             }
 #endif
             leaf_done = false;
-            if (tri_pass) {
-                if (in_leaf) {
-                    tr = ld_tri(leaf_verts + (size_t)ref * 9);
-                    if (tri_test<STATS>(gnormal, flags, tr, [&]() { return leaf_tris[ref]; }, o, d, md, best, l2, l3, n_tris)) {
-                        hit_ref = ref;
-                        if (any && sqr(best / rlen) < target) alive = false;
-                    }
-                    ++ref; --left;
-                    leaf_done = left == 0u;
+            // one trip for both kinds of lanes: everybody issues its loads, then everybody waits once
+            const bool at_node = alive && !in_leaf;
+            const uint32_t rec = node & 0x3fffffffu, sub = node >> 30;
+            u32x4 ra = {0u, 0u, 0u, 0u}, rb = {0u, 0u, 3u, 0u};
+            if (in_leaf) tr = ld_tri(leaf_verts + (size_t)ref * 9);
+            if (at_node) { ra = kd[2u * rec]; rb = kd[2u * rec + 1u]; }
+            asm volatile("" : "+v"(ra), "+v"(rb), "+v"(tr.A.x), "+v"(tr.A.y), "+v"(tr.A.z), "+v"(tr.AB.x), "+v"(tr.AB.y), "+v"(tr.AB.z),
+                              "+v"(tr.AC.x), "+v"(tr.AC.y), "+v"(tr.AC.z));
+            if (in_leaf) {
+                if (tri_test<STATS>(gnormal, flags, tr, [&]() { return leaf_tris[ref]; }, o, d, md, best, l2, l3, n_tris)) {
+                    hit_ref = ref;
+                    if (any && sqr(best / rlen) < target) alive = false;
                 }
-            } else if (alive && !in_leaf) {
-                const uint32_t rec = node & 0x3fffffffu, sub = node >> 30;
-                u32x4 ra = kd[2u * rec], rb = kd[2u * rec + 1u];          // one 32-byte record
-                asm volatile("" : "+v"(ra), "+v"(rb));
+                ++ref; --left;
+                leaf_done = left == 0u;
+            }
+            if (at_node) {
                 const uint32_t meta = rb.z;
                 if ((meta & 3u) == 3u) {                                  // leaf record
                     if (STATS) n_nodes++;
