@@ -30,7 +30,7 @@ def build_scene(args):
         env = os.path.join(data, "env", "forest")
         scene = host.Scene.synthetic(args.mesh_n, seed=42, width=args.width, height=args.height,
                                      max_trace_depth=args.depth, env_folder=env)
-        name = (f"synthetic displaced-grid glass mesh, {scene.desc.n_tris} triangles, midpoint KD-tree, "
+        name = (f"synthetic displaced-grid glass mesh, {scene.desc.n_tris} triangles, midpoint KD-tree from the host builder + device SAH refinement, "
                 f"{args.width}x{args.height}, maxTraceDepth {args.depth}, forest cubemap (BASELINE configs[4])")
     else:
         scene = host.Scene.load(os.path.join(data, args.workload))

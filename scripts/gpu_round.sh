@@ -12,3 +12,12 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 find "$OUT/ktrace" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats.csv"
 head -5 "$OUT/kernel_stats.csv"
 scripts/pmc_passes.sh "$1/pmc" > "$OUT/pmc.log" 2>&1; tail -30 "$OUT/pmc.log"
+# FETCH_SIZE calibration on a known number of random 128-byte line fetches (scripts/micro/gather.hip)
+if [ -x build_variants/gather ]; then
+  timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/cal" -- build_variants/gather cal > "$OUT/cal.log" 2>&1
+  python3 - "$OUT" <<'PY'
+import csv, glob, sys
+rows = [r for f in glob.glob(sys.argv[1] + "/cal/*/*counter_collection.csv") for r in csv.DictReader(open(f)) if "chase" in r["Kernel_Name"]]
+for r in rows: print("calibration", r["Kernel_Name"][:40], r["Counter_Name"], r["Counter_Value"])
+PY
+fi

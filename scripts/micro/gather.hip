@@ -38,7 +38,8 @@ void run(const char* name, const u32x4* arr, unsigned n_lines, unsigned* out, in
            ms * 1e6 / steps, lane_steps / ms / 1e6);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool calibrate = argc > 1;   // one case only: FETCH_SIZE calibration for 16-byte random gathers (lines = 4096 waves x 64 x 2200)
     const size_t max_lines = (size_t)1 << 24;        // 2 GiB
     u32x4* arr; unsigned* out;
     hipMalloc(&arr, max_lines * 128); hipMalloc(&out, 256 * 16 * 64 * 4);
@@ -46,6 +47,7 @@ int main() {
     unsigned x = 12345u;
     for (auto& w : h) { x = x * 1664525u + 1013904223u; w = x; }
     hipMemcpy(arr, h.data(), max_lines * 128, hipMemcpyHostToDevice);
+    if (calibrate) { run<1, 1>("1 x 16B", arr, 1u << 24, out, 16); return 0; }
     for (unsigned lines : {1u << 14, 1u << 19, 1u << 24}) {    // 2 MiB (L2), 64 MiB (MALL), 2 GiB (HBM)
         for (int w : {8, 16}) {
             run<1, 1>("1 x 16B", arr, lines, out, w);
