@@ -29,7 +29,12 @@ namespace {
 //   0..2 origin, 3..5 direction, 6 = (w.r, w.g), 7 = (w.b, flags|depth),
 //   radiance ray : 8 = path id (low 32 bits)
 //   shadow ray   : 8 = squared distance to the light, 9 = intensity / |ip - light|^2
-constexpr int kEntryWords = 10;
+constexpr int kEntryWords = 11;
+#ifndef QD_UNIT_SIDE
+#define QD_UNIT_SIDE 8
+#endif
+constexpr int kUnitSide = QD_UNIT_SIDE;                  // work unit = kUnitSide x kUnitSide pixels, handed to one wave
+constexpr uint32_t kUnitPx = kUnitSide * kUnitSide;
 constexpr uint32_t kFlagShadow = 0x80000000u, kFlagPrimary = 0x40000000u, kDepthMask = 0x00ffffffu;
 
 struct Params {
@@ -48,7 +53,8 @@ struct Params {
     uint64_t* stack;              // ray task workspace
     uint32_t stack_cap;           // slots per lane
     uint32_t n_lanes;
-    float* rgb; size_t pitch;     // output (pitch in floats, rectangle mode)
+    float* rgb; size_t pitch;     // output (pitch in floats, rectangle mode); zeroed by launch(), the kernel adds into it
+    size_t rgb_floats;            // floats of `rgb` this launch may write
     int32_t* hit_node; int32_t* hit_tri; double* hit_dist;
     unsigned long long* stats;    // 8 counters, see qd_stats
     int* error_flag;
@@ -60,6 +66,7 @@ struct Task {
     uint32_t flags_depth;
     uint32_t path;
     double aux0, aux1;
+    uint32_t pixel;               // output slot the ray's colour is added to (a task may be traced by any lane of the wave)
 };
 
 QD_DEV uint64_t pack2f(float a, float b) { return (uint64_t)__float_as_uint(a) | ((uint64_t)__float_as_uint(b) << 32); }
@@ -76,21 +83,24 @@ struct LaneQueue {
         p[7 * stride] = pack_fu(t.w.b, t.flags_depth);
         if (t.flags_depth & kFlagShadow) { p[8 * stride] = __double_as_longlong(t.aux0); p[9 * stride] = __double_as_longlong(t.aux1); }
         else p[8 * stride] = t.path;
+        p[10 * stride] = t.pixel;
         ++sp;
     }
-    QD_DEV Task pop() {
-        --sp;
-        const uint64_t* p = base + (size_t)sp * kEntryWords * stride;
+    // entry `idx` of the queue that starts at `b` (any lane's queue of this wave: same layout, base shifted by the lane)
+    static QD_DEV Task load(const uint64_t* b, size_t stride, int idx) {
+        const uint64_t* p = b + (size_t)idx * kEntryWords * stride;
         Task t;
         t.o = mk(__longlong_as_double(p[0 * stride]), __longlong_as_double(p[1 * stride]), __longlong_as_double(p[2 * stride]));
         t.d = mk(__longlong_as_double(p[3 * stride]), __longlong_as_double(p[4 * stride]), __longlong_as_double(p[5 * stride]));
-        const uint64_t a = p[6 * stride], b = p[7 * stride];
-        t.w = mkc(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)), __uint_as_float((uint32_t)b));
-        t.flags_depth = (uint32_t)(b >> 32);
+        const uint64_t a = p[6 * stride], w = p[7 * stride];
+        t.w = mkc(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)), __uint_as_float((uint32_t)w));
+        t.flags_depth = (uint32_t)(w >> 32);
         if (t.flags_depth & kFlagShadow) { t.aux0 = __longlong_as_double(p[8 * stride]); t.aux1 = __longlong_as_double(p[9 * stride]); t.path = 0; }
         else { t.path = (uint32_t)p[8 * stride]; t.aux0 = t.aux1 = 0; }
+        t.pixel = (uint32_t)p[10 * stride];
         return t;
     }
+    QD_DEV Task pop() { --sp; return load(base, stride, sp); }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -236,6 +246,7 @@ QD_DEV void eval_leaf_shader(const DScene& S, const Params& P, int si, Col w, ui
                 s.w = w * cl;
                 s.flags_depth = kFlagShadow | depth;
                 s.path = 0;
+                s.pixel = ray.pixel;
                 q.push(s);
             }
             break;
@@ -246,6 +257,7 @@ QD_DEV void eval_leaf_shader(const DScene& S, const Params& P, int si, Col w, ui
             r.o = info.ip + n * 0.000001;
             r.flags_depth = depth + 1;
             r.aux0 = r.aux1 = 0;
+            r.pixel = ray.pixel;
             if (sh.p1 == 1) {
                 r.d = reflect(ray.d, n);
                 r.w = w * (float)sh.p0;
@@ -283,6 +295,7 @@ QD_DEV void eval_leaf_shader(const DScene& S, const Params& P, int si, Col w, ui
             r.flags_depth = depth + 1;
             r.path = path_child(ray.path, slot, 0);
             r.aux0 = r.aux1 = 0;
+            r.pixel = ray.pixel;
             q.push(r);
             break;
         }
@@ -290,18 +303,21 @@ QD_DEV void eval_leaf_shader(const DScene& S, const Params& P, int si, Col w, ui
     }
 }
 
-QD_DEV uint32_t fetch_unit(const Params& P, uint32_t home) {
+// Hands out `want` consecutive pixel slots (slot = unit * kUnitPx + pixel inside the unit, so consecutive slots are
+// neighbours on screen) from the eight XCD-labelled queues, the caller's own queue first.  Returns the number granted
+// (0 = every queue is exhausted) and the first slot.
+QD_DEV uint32_t fetch_slots(const Params& P, uint32_t home, uint32_t want, uint32_t& first) {
     const uint32_t per = (P.n_units + 7u) / 8u;
     for (uint32_t i = 0; i < 8; ++i) {
         const uint32_t qi = (home + i) & 7u;
         const uint32_t lo = qi * per;
         if (lo >= P.n_units) continue;
-        const uint32_t size = min(per, P.n_units - lo);
+        const uint32_t size = min(per, P.n_units - lo) * kUnitPx;
         if (__hip_atomic_load(&P.queue_ctr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= size) continue;
-        const uint32_t v = atomicAdd(&P.queue_ctr[qi], 1u);
-        if (v < size) return lo + v;
+        const uint32_t v = atomicAdd(&P.queue_ctr[qi], want);
+        if (v < size) { first = lo * kUnitPx + v; return min(want, size - v); }
     }
-    return 0xffffffffu;
+    return 0u;
 }
 
 QD_DEV uint32_t wave_sum(uint32_t v) {
@@ -315,14 +331,35 @@ QD_DEV uint32_t wave_sum(uint32_t v) {
 #endif
 constexpr uint32_t kWavesPerCU = 4 * QD_WAVES_PER_EU;
 
+// position of the r-th (0-based) set bit of m
+QD_DEV uint32_t nth_set_bit(unsigned long long m, uint32_t r) {
+    uint32_t pos = 0;
+#pragma unroll
+    for (uint32_t w = 32; w >= 1; w >>= 1) {
+        const uint32_t c = (uint32_t)__popcll(m & (((1ull << w) - 1ull) << pos));
+        if (r >= c) { r -= c; pos += w; }
+    }
+    return pos;
+}
+
+// vfb[y][x] += colour.  The reference assigns Raytrace()'s return value once (src/main.cpp:96); here the value is the
+// sum of the contributions of the pixel's ray tasks, which any lane of the wave may have traced, so they are added
+// with hardware float atomics into a buffer zeroed before the launch.  Tasks of one pixel handled by one lane arrive
+// in program order; only pixels whose tasks were shared between lanes see a different order of additions.
+QD_DEV void add_px(const Params& P, uint32_t pixel, const Col& c) {
+    if (c.r == 0.f && c.g == 0.f && c.b == 0.f) return;
+    float* o = P.rgb + (P.mode == 0 ? (size_t)(pixel / (uint32_t)P.rw) * P.pitch + (size_t)(pixel % (uint32_t)P.rw) * 3 : (size_t)pixel * 3);
+    unsafeAtomicAdd(o, c.r); unsafeAtomicAdd(o + 1, c.g); unsafeAtomicAdd(o + 2, c.b);
+}
+
 struct PixelSlot { int x, y; uint32_t out_idx; bool valid; uint32_t tap; };
 
 QD_DEV PixelSlot map_pixel(const Params& P, uint32_t unit, uint32_t p) {
     PixelSlot s;
     s.tap = 0;
-    const int lx8 = p & 7, ly8 = p >> 3;
+    const int lx8 = (int)(p % (uint32_t)kUnitSide), ly8 = (int)(p / (uint32_t)kUnitSide);
     if (P.mode == 2) {
-        const uint32_t j = unit * 64u + p;
+        const uint32_t j = unit * kUnitPx + p;
         s.valid = j < P.n_samples;
         const uint32_t xy = s.valid ? P.aa_pixels[j >> 2] : 0u;
         s.x = (int)(xy & 0xffffu); s.y = (int)(xy >> 16);
@@ -330,16 +367,16 @@ QD_DEV PixelSlot map_pixel(const Params& P, uint32_t unit, uint32_t p) {
         s.out_idx = j;
     } else if (P.mode == 0) {
         const int ux = unit % P.units_x, uy = unit / P.units_x;
-        const int px = ux * 8 + lx8, py = uy * 8 + ly8;
+        const int px = ux * kUnitSide + lx8, py = uy * kUnitSide + ly8;
         s.x = P.x0 + px; s.y = P.y0 + py;
         s.valid = px < P.rw && py < P.rh;
         s.out_idx = (uint32_t)py * (uint32_t)P.rw + (uint32_t)px;
     } else {
-        const int sub_per_side = P.tile / 8, spt = sub_per_side * sub_per_side;
+        const int sub_per_side = P.tile / kUnitSide, spt = sub_per_side * sub_per_side;
         const int k = unit / spt, sb = unit % spt;
         const int t = P.phase + k * P.stride;
         const int tx = t % P.tiles_x, ty = t / P.tiles_x;
-        const int lx = (sb % sub_per_side) * 8 + lx8, ly = (sb / sub_per_side) * 8 + ly8;
+        const int lx = (sb % sub_per_side) * kUnitSide + lx8, ly = (sb / sub_per_side) * kUnitSide + ly8;
         s.x = tx * P.tile + lx; s.y = ty * P.tile + ly;
         s.valid = s.x < P.W && s.y < P.H;
         s.out_idx = (uint32_t)k * (uint32_t)(P.tile * P.tile) + (uint32_t)(ly * P.tile + lx);
@@ -360,33 +397,25 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
     unsigned long long t_trace = 0, t_shade = 0, t_sched = 0;
     const unsigned long long t_begin = QD_STAMP();
 
-    uint32_t unit = 0, unit_next = 64;     // wave-uniform: current unit and its first unassigned pixel
     bool pool_empty = false;
-    bool have_px = false;
-    uint32_t out_idx = 0;
-    Col acc = mkc(0, 0, 0);
+    unsigned long long t_pool_empty = 0;
+    const uint64_t* wave_base = P.stack + (size_t)blockIdx.x * 64;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
     for (;;) {
         const unsigned long long tp0 = QD_STAMP();
-        if (have_px && q.sp == 0) {        // pixel finished: write it (vfb[y][x] = Raytrace(...), src/main.cpp:96)
-            float* o = P.rgb + (P.mode == 0 ? (size_t)(out_idx / (uint32_t)P.rw) * P.pitch + (size_t)(out_idx % (uint32_t)P.rw) * 3
-                                            : (size_t)out_idx * 3);
-            o[0] = acc.r; o[1] = acc.g; o[2] = acc.b;
-            have_px = false;
-        }
-        unsigned long long idle = __ballot(!have_px);
+        // 1. lanes whose queue is empty take the next pixels of the frame: one atomic per wave and round, pixel
+        //    granularity, so a region of heavy pixels (hundreds of rays each behind glass) is spread over many waves
+        unsigned long long idle = __ballot(q.sp == 0);
         while (idle != 0ull && !pool_empty) {
-            if (unit_next >= 64u) {
-                uint32_t u = 0;
-                if (lane == 0) u = fetch_unit(P, blockIdx.x & 7u);
-                u = __shfl(u, 0, 64);
-                if (u == 0xffffffffu) { pool_empty = true; break; }
-                unit = u; unit_next = 0;
-            }
-            const uint32_t avail = 64u - unit_next;
-            const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
-            if (!have_px && rank < avail) {
-                const PixelSlot px = map_pixel(P, unit, unit_next + rank);
+            uint32_t first = 0, got = 0;
+            if (lane == 0) got = fetch_slots(P, blockIdx.x & 7u, (uint32_t)__popcll(idle), first);
+            got = __shfl(got, 0, 64); first = __shfl(first, 0, 64);
+            if (got == 0u) { pool_empty = true; t_pool_empty = QD_STAMP(); break; }
+            const uint32_t rank = __popcll(idle & lanes_below);
+            if (q.sp == 0 && rank < got) {
+                const uint32_t slot = first + rank;
+                const PixelSlot px = map_pixel(P, slot / kUnitPx, slot % kUnitPx);
                 if (px.valid) {
                     // Camera::GetScreenRay, src/camera.cpp:26-41 (integer pixel coordinates, no +0.5)
                     const DV TL = ld3(P.cam.top_left), TR = ld3(P.cam.top_right), BL = ld3(P.cam.bottom_left), pos = ld3(P.cam.position);
@@ -400,22 +429,60 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
                     t.flags_depth = kFlagPrimary;
                     t.path = pixel_path(px.x, px.y, px.tap);
                     t.aux0 = t.aux1 = 0;
+                    t.pixel = px.out_idx;
                     q.push(t);
                     ++n_primary;
-                    have_px = true; out_idx = px.out_idx; acc = mkc(0, 0, 0);
                 }
             }
-            const uint32_t n_idle = __popcll(idle);
-            unit_next += n_idle < avail ? n_idle : avail;
-            idle = __ballot(!have_px);
+            idle = __ballot(q.sp == 0);
         }
-        if (__ballot(have_px) == 0ull) break;      // pool empty and nothing in flight in this wave
-        if (!have_px) continue;
+        // 2. every lane with work takes its newest task
+        bool have = q.sp > 0;
+        Task t;
+        if (have) t = q.pop();
+        // 3. lanes left without work take the next task of a lane that has more: the ray tree of one heavy pixel
+        //    (hundreds of rays behind glass) spreads over the wave instead of running on one lane while 63 wait
+        const unsigned long long m_need = __ballot(!have);
+        if (m_need != 0ull) {
+            // every queued task of the wave is on offer: the r-th lane in need takes the r-th task counted over the
+            // lanes' queues from their tops down (inclusive scan of the queue depths, then a search in it)
+            const uint32_t mine = (uint32_t)q.sp;
+            uint32_t incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += v; }
+            const uint32_t total = __shfl(incl, 63, 64);
+            if (total != 0u) {
+                const uint32_t n_need = (uint32_t)__popcll(m_need);
+                const uint32_t n_take = n_need < total ? n_need : total;
+                const uint32_t r = (uint32_t)__popcll(m_need & lanes_below);
+                const bool takes = !have && r < n_take;
+                uint32_t lo = 0, hi = 63;                      // smallest lane whose inclusive count exceeds r
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint32_t v = __shfl(incl, (int)mid, 64);
+                    if (v > r) hi = mid; else lo = mid + 1;
+                }
+                const uint32_t src = takes ? lo : lane;
+                const uint32_t src_incl = __shfl(incl, (int)src, 64), src_sp = __shfl(mine, (int)src, 64);
+                if (takes) {
+                    const uint32_t k = r - (src_incl - src_sp);                   // k-th from the donor's top
+                    t = LaneQueue::load(wave_base + src, q.stride, (int)(src_sp - 1u - k));
+                    have = true;
+                }
+                const uint32_t excl = incl - mine;
+                const uint32_t gives = n_take > excl ? (n_take - excl < mine ? n_take - excl : mine) : 0u;
+                q.sp -= (int)gives;
+            }
+        }
+        if (__ballot(have) == 0ull) break;         // pool empty and no task left in this wave
+        if (!have) continue;
 
-        const Task t = q.pop();
+        Col acc = mkc(0, 0, 0);                    // this task's own colour
+        do {
         const bool shadow = (t.flags_depth & kFlagShadow) != 0;
         const uint32_t depth = t.flags_depth & kDepthMask;
-        if (!shadow && depth > P.max_depth) { ++n_killed; continue; }          // src/main.cpp:20-21
+        if (!shadow && depth > P.max_depth) { ++n_killed; break; }             // src/main.cpp:20-21
         if (shadow) ++n_shadow; else ++n_rays;
         GHit h; double dw; float transp;
         const unsigned long long tp1 = QD_STAMP();
@@ -425,16 +492,16 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
         t_trace += tp2 - tp1;
         if (shadow) {
             acc = acc + t.w * (float)((double)transp * t.aux1);
-            continue;
+            break;
         }
         if ((t.flags_depth & kFlagPrimary) && P.hit_node) {
-            P.hit_node[out_idx] = node;
-            P.hit_tri[out_idx] = node >= 0 ? h.tri : -1;
-            P.hit_dist[out_idx] = node >= 0 ? dw : 0.;
+            P.hit_node[t.pixel] = node;
+            P.hit_tri[t.pixel] = node >= 0 ? h.tri : -1;
+            P.hit_dist[t.pixel] = node >= 0 ? dw : 0.;
         }
         if (node < 0) {
             if (S.env_present) acc = acc + t.w * env_lookup(S, t.d);
-            continue;
+            break;
         }
         const qd_node& n = S.nodes[node];
         Info info;
@@ -456,11 +523,16 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
             eval_leaf_shader(S, P, n.shader, t.w, 0, t, depth, info, acc, q);
         }
         t_shade += QD_STAMP() - tp2;
+        } while (false);
+        add_px(P, t.pixel, acc);
     }
 #ifdef QD_PROFILE
     if (P.stats) { atomicAdd(&P.stats[12], cnt.t_desc); atomicAdd(&P.stats[13], cnt.t_leaf); }   // lane / wave iterations of the KD loop
     if (P.stats && lane == 0) {   // diagnostic build: wave-cycle shares go to their own words, never into outputs
-        atomicAdd(&P.stats[8], QD_STAMP() - t_begin);
+        const unsigned long long t_end = QD_STAMP();
+        atomicMin(&P.stats[16], t_begin); atomicMax(&P.stats[17], t_end); atomicMax(&P.stats[18], t_pool_empty);
+        atomicMin(&P.stats[19], t_pool_empty ? t_pool_empty : ~0ull); atomicAdd(&P.stats[20], t_end - t_begin);
+        atomicAdd(&P.stats[8], t_end - t_begin);
         atomicAdd(&P.stats[9], t_sched); atomicAdd(&P.stats[10], t_trace); atomicAdd(&P.stats[11], t_shade);
         atomicAdd(&P.stats[14], cnt.t_a); atomicAdd(&P.stats[15], cnt.t_b); atomicAdd(&P.stats[7], cnt.t_c); atomicAdd(&P.stats[6], cnt.t_d);
     }
@@ -660,6 +732,7 @@ int launch(qd_scene* s, Params& P, hipStream_t stream) {
     P.queue_ctr = s->queue_ctr; P.stack = s->stack; P.stack_cap = s->stack_cap; P.n_lanes = s->n_lanes;
     P.error_flag = s->error_flag;
     HIP_TRY(hipMemsetAsync(s->queue_ctr, 0, 8 * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));       // the kernel adds colours into it
     const uint32_t max_blocks = s->n_lanes / 64;
     const uint32_t grid = P.n_units < max_blocks ? (P.n_units ? P.n_units : 1) : max_blocks;
     if (g_counting) hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(64), 0, stream, s->d, P);
@@ -863,7 +936,7 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     s->spawn0 = spawn0; s->spawn1 = spawn1;
     s->n_lanes = (uint32_t)(g_num_cu > 0 ? g_num_cu : 256) * kWavesPerCU * 64u;
     if (!rc && hipMalloc((void**)&s->queue_ctr, 8 * sizeof(uint32_t)) != hipSuccess) rc = set_err("hipMalloc(queue counters) failed");
-    if (!rc && hipMalloc((void**)&s->stats, 16 * sizeof(unsigned long long)) != hipSuccess) rc = set_err("hipMalloc(stats) failed");
+    if (!rc && hipMalloc((void**)&s->stats, 24 * sizeof(unsigned long long)) != hipSuccess) rc = set_err("hipMalloc(stats) failed");
     if (!rc && hipMalloc((void**)&s->error_flag, sizeof(int)) != hipSuccess) rc = set_err("hipMalloc(error flag) failed");
     if (!rc && hipMemset(s->error_flag, 0, sizeof(int)) != hipSuccess) rc = set_err("hipMemset failed");
     if (!rc) rc = ensure_stack(s, desc->settings.max_trace_depth);
@@ -892,8 +965,8 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
     if (ensure_stack(s, st->max_trace_depth)) return -1;
     Params P; fill_common(P, cam, st);
     P.mode = 0; P.x0 = x0; P.y0 = y0; P.rw = rw; P.rh = rh;
-    P.units_x = (uint32_t)(rw + 7) / 8;
-    P.n_units = P.units_x * (uint32_t)((rh + 7) / 8);
+    P.units_x = (uint32_t)(rw + kUnitSide - 1) / kUnitSide;
+    P.n_units = P.units_x * (uint32_t)((rh + kUnitSide - 1) / kUnitSide);
     const size_t npx = (size_t)rw * rh;
     float* d_rgb = nullptr; int32_t* d_hn = nullptr; int32_t* d_ht = nullptr; double* d_hd = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -909,9 +982,10 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
         TRY2(hipMalloc((void**)&d_ht, npx * sizeof(int32_t)));
         TRY2(hipMalloc((void**)&d_hd, npx * sizeof(double)));
     }
-    P.rgb = d_rgb; P.pitch = (size_t)rw * 3; P.hit_node = d_hn; P.hit_tri = d_ht; P.hit_dist = d_hd;
+    P.rgb = d_rgb; P.pitch = (size_t)rw * 3; P.rgb_floats = npx * 3; P.hit_node = d_hn; P.hit_tri = d_ht; P.hit_dist = d_hd;
     P.stats = s->stats;
-    TRY2(hipMemsetAsync(s->stats, 0, 16 * sizeof(unsigned long long), nullptr));
+    TRY2(hipMemsetAsync(s->stats, 0, 24 * sizeof(unsigned long long), nullptr));
+    TRY2(hipMemsetAsync(s->stats + 16, 0xff, sizeof(unsigned long long), nullptr)); TRY2(hipMemsetAsync(s->stats + 19, 0xff, sizeof(unsigned long long), nullptr));
     TRY2(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
     TRY2(hipEventCreate(&e0)); TRY2(hipEventCreate(&e1));
     TRY2(hipEventRecord(e0, nullptr));
@@ -930,9 +1004,11 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
         TRY2(hipMemcpy(hit_dist, d_hd, npx * sizeof(double), hipMemcpyDeviceToHost));
     }
     if (stats) {
-        unsigned long long h[16];
+        unsigned long long h[24];
         TRY2(hipMemcpy(h, s->stats, sizeof h, hipMemcpyDeviceToHost));
 #ifdef QD_PROFILE
+        fprintf(stderr, "[qd profile] timeline (ticks since first wave start): first pool-empty %llu, last pool-empty %llu, last wave end %llu, mean wave life %llu\n",
+                h[19] - h[16], h[18] - h[16], h[17] - h[16], h[20] / 4096);
         fprintf(stderr, "[qd profile] wave-cycles total %llu sched %llu trace %llu shade %llu | kd lane-iters %llu wave-iters %llu | xform %llu mesh %llu analytic %llu bookkeeping %llu\n", h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[7], h[6]);
 #endif
         stats->rays = h[0]; stats->primary_rays = h[1]; stats->shadow_rays = h[2]; stats->depth_killed = h[3];
@@ -970,7 +1046,8 @@ extern "C" int qd_antialias(qd_scene* s, const qd_camera* cam, const qd_settings
     TRY2(hipMalloc((void**)&d_changed, sizeof(int)));
     TRY2(hipMemcpy2D(d_first, (size_t)W * 3 * sizeof(float), rgb, pitch * sizeof(float), (size_t)W * 3 * sizeof(float), H, hipMemcpyHostToDevice));
     TRY2(hipMemset(d_count, 0, sizeof(uint32_t)));
-    TRY2(hipMemsetAsync(s->stats, 0, 16 * sizeof(unsigned long long), nullptr));
+    TRY2(hipMemsetAsync(s->stats, 0, 24 * sizeof(unsigned long long), nullptr));
+    TRY2(hipMemsetAsync(s->stats + 16, 0xff, sizeof(unsigned long long), nullptr)); TRY2(hipMemsetAsync(s->stats + 19, 0xff, sizeof(unsigned long long), nullptr));
     TRY2(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
     const dim3 blk(64), grd((unsigned)(W + 63) / 64, (unsigned)H);
     hipLaunchKernelGGL(aa_mark_kernel, grd, blk, 0, nullptr, d_first, W, H, st->want_adaptive_aa, st->aa_threshold, d_slot, d_list, d_count);
@@ -982,8 +1059,8 @@ extern "C" int qd_antialias(qd_scene* s, const qd_camera* cam, const qd_settings
         TRY2(hipMalloc((void**)&d_aa, (size_t)n_list * 3 * sizeof(float)));
         Params P; fill_common(P, cam, st);
         P.mode = 2; P.aa_pixels = d_list; P.n_samples = n_list * 4u;
-        P.n_units = (P.n_samples + 63u) / 64u;
-        P.rgb = d_taps; P.stats = s->stats;
+        P.n_units = (P.n_samples + kUnitPx - 1u) / kUnitPx;
+        P.rgb = d_taps; P.rgb_floats = (size_t)P.n_samples * 3; P.stats = s->stats;
         TRY2(hipEventCreate(&e0)); TRY2(hipEventCreate(&e1));
         TRY2(hipEventRecord(e0, nullptr));
         if (launch(s, P, nullptr)) { cleanup(); return -1; }
@@ -1036,8 +1113,8 @@ extern "C" int qd_render_tiles_async(qd_scene* s, const qd_camera* cam, const qd
     const int tiles_y = (st->frame_height + tile - 1) / tile;
     const int n_tiles = P.tiles_x * tiles_y;
     const int n_owned = n_tiles > tile_phase ? (n_tiles - tile_phase + tile_stride - 1) / tile_stride : 0;
-    P.n_units = (uint32_t)n_owned * (uint32_t)((tile / 8) * (tile / 8));
-    P.rgb = rgb_dev;
+    P.n_units = (uint32_t)n_owned * (uint32_t)((tile / kUnitSide) * (tile / kUnitSide));
+    P.rgb = rgb_dev; P.rgb_floats = (size_t)n_owned * tile * tile * 3;
     P.stats = (unsigned long long*)stats_dev;   // first 7 fields of qd_stats are the 64-bit counters
     if (stats_dev) HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(qd_stats), stream));
     if (P.n_units == 0) return 0;

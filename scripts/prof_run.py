@@ -7,6 +7,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2240
 s = host.Scene.synthetic(n, 42, 3840, 2160, 8, os.path.join(ROOT, "tests/golden/data/env/forest"))
 device.init(0)
 ds = device.DeviceScene(s)
+rect = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 0, 3840, 2160]
 for i in range(2):
-    rgb, _, st = ds.render()
+    rgb, _, st = ds.render(*rect)
     print({k: st[k] for k in ("rays", "kernel_ms")}, flush=True)

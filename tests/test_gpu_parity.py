@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 COLOUR_TOL = 1e-4
 NEAR_TIE_BUDGET = 1e-4     # 0.01 % of pixels
+SUM_ORDER_TOL = 2e-6       # two device renders of the same pixel: float additions in a different order
 
 SCENES = ["hw9/nonconvex.qdmg", "window_fixed.qdmg", "bumpmap_fixed.qdmg", "lecture7_fixed.qdmg",
           "heightfield_fixed.qdmg", "kdtree_teapot_lowres_env.qdmg", "kdtree_teapot_hires_sah_noenv.qdmg",
@@ -80,7 +81,9 @@ def test_ragged_rectangles_and_pitch(load_scene):
         full, _, _ = ds.render()
         for (x0, y0, x1, y1) in [(0, 0, 1, 1), (5, 7, 6, 20), (633, 471, 640, 480), (100, 100, 173, 131)]:
             part, hits, st = ds.render(x0, y0, x1, y1, hits=True)
-            assert np.array_equal(part, full[y0:y1, x0:x1])
+            # a pixel's colour is the sum of its ray tasks' contributions; tasks that were shared between lanes of a wave
+            # are added in a different order, so two renders agree to float rounding, not to the bit
+            assert np.abs(part - full[y0:y1, x0:x1]).max() <= SUM_ORDER_TOL
             assert st["primary_rays"] == (x1 - x0) * (y1 - y0)
         with pytest.raises(device.DeviceError):
             ds.render(10, 10, 10, 20)            # empty rectangle is rejected, like a bad bucket
@@ -91,7 +94,7 @@ def test_ragged_rectangles_and_pitch(load_scene):
 
 
 def test_tile_sharded_frame_equals_single_rectangle(load_scene):
-    """render(N shards) == render(1 GPU) bytewise: pixels are independent."""
+    """render(N shards) == render(1 GPU) up to the order of float additions: pixels are independent."""
     import torch
     s = load_scene("heightfield_fixed.qdmg")
     s.settings.want_aa = 0
@@ -109,8 +112,9 @@ def test_tile_sharded_frame_equals_single_rectangle(load_scene):
             device.untile_async(gathered.data_ptr(), frame.data_ptr(), W, H, tile, world, tpr)
             torch.cuda.synchronize()
             ds.check()
-            assert np.array_equal(frame.cpu().numpy(), full)
-            assert np.array_equal(sharding.untile(gathered.cpu().numpy(), W, H, tile, world), full)
+            got = frame.cpu().numpy()
+            assert np.array_equal(sharding.untile(gathered.cpu().numpy(), W, H, tile, world), got)   # de-interleave is exact
+            assert np.abs(got - full).max() <= SUM_ORDER_TOL
     finally:
         ds.close()
 
