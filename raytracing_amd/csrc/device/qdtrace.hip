@@ -22,6 +22,11 @@
 
 using namespace qd;
 
+#ifdef QD_NO_OUTLINE
+#define QD_OUTLINE __forceinline__
+#else
+#define QD_OUTLINE __attribute__((noinline))
+#endif
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -35,6 +40,8 @@ constexpr int kEntryWords = 11;
 #endif
 constexpr int kUnitSide = QD_UNIT_SIDE;                  // work unit = kUnitSide x kUnitSide pixels, handed to one wave
 constexpr uint32_t kUnitPx = kUnitSide * kUnitSide;
+constexpr uint32_t kCtlStride = 32;                      // control words sit 128 bytes apart: one cache line each, so the waves'
+                                                         // atomics on one counter do not queue up behind those on its neighbours
 constexpr uint32_t kFlagShadow = 0x80000000u, kFlagPrimary = 0x40000000u, kDepthMask = 0x00ffffffu;
 
 struct Params {
@@ -49,7 +56,7 @@ struct Params {
     int tile, tiles_x, phase, stride;
     uint32_t n_units;             // 8x8 pixel units to render
     uint32_t units_x;             // rectangle mode: units per row
-    uint32_t* queue_ctr;          // 8 work-queue counters (zeroed before launch)
+    uint32_t* queue_ctr;          // 8 work-queue counters, kCtlStride words apart (zeroed before launch)
     uint64_t* stack;              // ray task workspace
     uint32_t stack_cap;           // slots per lane
     uint32_t n_lanes;
@@ -114,7 +121,7 @@ struct LaneQueue {
 //    (ShadingHelper::GetShadowTransparency, src/shadinghelper.cpp:20-40).  Once the product is exactly 0
 //    no later factor can change it, so the node loop stops there.
 template <bool STATS>
-QD_DEV int trace_nodes(const DScene& S, const DV& o, const DV& d, bool shadow, double target,
+__device__ QD_OUTLINE int trace_nodes(const DScene& S, const DV& o, const DV& d, bool shadow, double target,
                        float& transp, double& best_dw, GHit& hit, Counters& cnt) {
     int best_node = -1;
     best_dw = kInf; transp = 1.f;
@@ -197,7 +204,7 @@ QD_DEV void assemble_info(const DScene& S, const qd_node& n, GHit& h, double dw,
 
 // One non-layered shader at a hit: adds its direct colour to acc and queues its rays
 // (Lambert/Phong/BlinnPhong/OrenNayar/Const/Reflection/Refraction::Shade, src/shading.cpp).
-QD_DEV void eval_leaf_shader(const DScene& S, const Params& P, int si, Col w, uint32_t slot, const Task& ray, uint32_t depth,
+__device__ QD_OUTLINE void eval_leaf_shader(const DScene& S, const Params& P, int si, Col w, uint32_t slot, const Task& ray, uint32_t depth,
                              const Info& info, Col& acc, LaneQueue& q) {
     const qd_shader sh = S.shaders[si];
     switch (sh.type) {
@@ -307,15 +314,16 @@ QD_DEV void eval_leaf_shader(const DScene& S, const Params& P, int si, Col w, ui
 // neighbours on screen) from the eight XCD-labelled queues, the caller's own queue first.  Returns the number granted
 // (0 = every queue is exhausted) and the first slot.
 QD_DEV uint32_t fetch_slots(const Params& P, uint32_t home, uint32_t want, uint32_t& first) {
-    const uint32_t per = (P.n_units + 7u) / 8u;
+    const uint32_t n_slots = P.n_units * kUnitPx;
+    const uint32_t per = ((n_slots + 7u) / 8u + kUnitPx - 1u) / kUnitPx * kUnitPx;      // whole units per queue
     for (uint32_t i = 0; i < 8; ++i) {
         const uint32_t qi = (home + i) & 7u;
         const uint32_t lo = qi * per;
-        if (lo >= P.n_units) continue;
-        const uint32_t size = min(per, P.n_units - lo) * kUnitPx;
-        if (__hip_atomic_load(&P.queue_ctr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= size) continue;
-        const uint32_t v = atomicAdd(&P.queue_ctr[qi], want);
-        if (v < size) { first = lo * kUnitPx + v; return min(want, size - v); }
+        if (lo >= n_slots) continue;
+        const uint32_t size = min(per, n_slots - lo);
+        if (__hip_atomic_load(&P.queue_ctr[qi * kCtlStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= size) continue;
+        const uint32_t v = atomicAdd(&P.queue_ctr[qi * kCtlStride], want);
+        if (v < size) { first = lo + v; return min(want, size - v); }
     }
     return 0u;
 }
@@ -440,8 +448,8 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
         bool have = q.sp > 0;
         Task t;
         if (have) t = q.pop();
-        // 3. lanes left without work take the next task of a lane that has more: the ray tree of one heavy pixel
-        //    (hundreds of rays behind glass) spreads over the wave instead of running on one lane while 63 wait
+        // 3. lanes left without work (no pixels left to hand out) take queued tasks of other lanes of the wave: the ray
+        //    tree of one heavy pixel (hundreds of rays behind glass) spreads over the wave instead of running on one lane
         const unsigned long long m_need = __ballot(!have);
         if (m_need != 0ull) {
             // every queued task of the wave is on offer: the r-th lane in need takes the r-th task counted over the
@@ -695,7 +703,7 @@ struct qd_scene {
     uint32_t stack_cap = 0;
     uint32_t n_lanes = 0;
     uint64_t* stack = nullptr;
-    uint32_t* queue_ctr = nullptr;       // 8 counters
+    uint32_t* queue_ctr = nullptr;       // 8 work-queue counters, one cache line each (kCtlStride words apart)
     unsigned long long* stats = nullptr; // 8 counters
     int* error_flag = nullptr;
     uint32_t spawn0 = 1, spawn1 = 1;     // tasks queued per hit at depth 0 / deeper
@@ -731,7 +739,7 @@ int ensure_stack(qd_scene* s, uint32_t max_depth) {
 int launch(qd_scene* s, Params& P, hipStream_t stream) {
     P.queue_ctr = s->queue_ctr; P.stack = s->stack; P.stack_cap = s->stack_cap; P.n_lanes = s->n_lanes;
     P.error_flag = s->error_flag;
-    HIP_TRY(hipMemsetAsync(s->queue_ctr, 0, 8 * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(s->queue_ctr, 0, 8 * kCtlStride * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));       // the kernel adds colours into it
     const uint32_t max_blocks = s->n_lanes / 64;
     const uint32_t grid = P.n_units < max_blocks ? (P.n_units ? P.n_units : 1) : max_blocks;
@@ -935,7 +943,7 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     for (int f = 0; f < 6; ++f) d.env_faces[f] = desc->env_faces[f];
     s->spawn0 = spawn0; s->spawn1 = spawn1;
     s->n_lanes = (uint32_t)(g_num_cu > 0 ? g_num_cu : 256) * kWavesPerCU * 64u;
-    if (!rc && hipMalloc((void**)&s->queue_ctr, 8 * sizeof(uint32_t)) != hipSuccess) rc = set_err("hipMalloc(queue counters) failed");
+    if (!rc && hipMalloc((void**)&s->queue_ctr, 8 * kCtlStride * sizeof(uint32_t)) != hipSuccess) rc = set_err("hipMalloc(queue counters) failed");
     if (!rc && hipMalloc((void**)&s->stats, 24 * sizeof(unsigned long long)) != hipSuccess) rc = set_err("hipMalloc(stats) failed");
     if (!rc && hipMalloc((void**)&s->error_flag, sizeof(int)) != hipSuccess) rc = set_err("hipMalloc(error flag) failed");
     if (!rc && hipMemset(s->error_flag, 0, sizeof(int)) != hipSuccess) rc = set_err("hipMemset failed");
