@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
     const unsigned long long t_begin = QD_STAMP();
 
     bool pool_empty = false;
-    unsigned long long t_pool_empty = 0;
+    unsigned long long t_pool_empty = 0, dbg_rounds = 0, dbg_tasks = 0, dbg_rounds_after = 0, dbg_tasks_after = 0;   // QD_PROFILE diagnostics
     const uint64_t* wave_base = P.stack + (size_t)blockIdx.x * 64;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
@@ -484,6 +484,10 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
             }
         }
         if (__ballot(have) == 0ull) break;         // pool empty and no task left in this wave
+#ifdef QD_PROFILE
+        { const unsigned long long n = (unsigned long long)__popcll(__ballot(have));
+          dbg_rounds += 1; dbg_tasks += n; if (pool_empty) { dbg_rounds_after += 1; dbg_tasks_after += n; } }
+#endif
         if (!have) continue;
 
         Col acc = mkc(0, 0, 0);                    // this task's own colour
@@ -538,6 +542,8 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
     if (P.stats) { atomicAdd(&P.stats[12], cnt.t_desc); atomicAdd(&P.stats[13], cnt.t_leaf); }   // lane / wave iterations of the KD loop
     if (P.stats && lane == 0) {   // diagnostic build: wave-cycle shares go to their own words, never into outputs
         const unsigned long long t_end = QD_STAMP();
+        { unsigned long long* w = P.stats + 24 + 6 * (size_t)(blockIdx.x & 4095u);
+          w[0] = t_end - t_begin; w[1] = t_pool_empty ? t_pool_empty - t_begin : 0ull; w[2] = dbg_rounds; w[3] = dbg_tasks; w[4] = dbg_rounds_after; w[5] = dbg_tasks_after; }
         atomicMin(&P.stats[16], t_begin); atomicMax(&P.stats[17], t_end); atomicMax(&P.stats[18], t_pool_empty);
         atomicMin(&P.stats[19], t_pool_empty ? t_pool_empty : ~0ull); atomicAdd(&P.stats[20], t_end - t_begin);
         atomicAdd(&P.stats[8], t_end - t_begin);
@@ -944,7 +950,7 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     s->spawn0 = spawn0; s->spawn1 = spawn1;
     s->n_lanes = (uint32_t)(g_num_cu > 0 ? g_num_cu : 256) * kWavesPerCU * 64u;
     if (!rc && hipMalloc((void**)&s->queue_ctr, 8 * kCtlStride * sizeof(uint32_t)) != hipSuccess) rc = set_err("hipMalloc(queue counters) failed");
-    if (!rc && hipMalloc((void**)&s->stats, 24 * sizeof(unsigned long long)) != hipSuccess) rc = set_err("hipMalloc(stats) failed");
+    if (!rc && hipMalloc((void**)&s->stats, (24 + 6 * 4096) * sizeof(unsigned long long)) != hipSuccess) rc = set_err("hipMalloc(stats) failed");
     if (!rc && hipMalloc((void**)&s->error_flag, sizeof(int)) != hipSuccess) rc = set_err("hipMalloc(error flag) failed");
     if (!rc && hipMemset(s->error_flag, 0, sizeof(int)) != hipSuccess) rc = set_err("hipMemset failed");
     if (!rc) rc = ensure_stack(s, desc->settings.max_trace_depth);
@@ -1015,6 +1021,15 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
         unsigned long long h[24];
         TRY2(hipMemcpy(h, s->stats, sizeof h, hipMemcpyDeviceToHost));
 #ifdef QD_PROFILE
+        { std::vector<unsigned long long> w(6 * 4096);
+          (void)hipMemcpy(w.data(), s->stats + 24, w.size() * 8, hipMemcpyDeviceToHost);
+          std::vector<int> idx(4096); for (int i = 0; i < 4096; ++i) idx[i] = i;
+          std::sort(idx.begin(), idx.end(), [&](int a, int b) { return w[6 * a] > w[6 * b]; });
+          for (int k : {0, 1, 16, 256, 1024, 2048, 3072, 4095}) { const int i = idx[k];
+              fprintf(stderr, "[qd profile] wave #%d by life: life %llu ticks, pool empty at %llu, %llu rounds / %llu tasks in all, %llu rounds / %llu tasks after\n",
+                      k, w[6 * i], w[6 * i + 1], w[6 * i + 2], w[6 * i + 3], w[6 * i + 4], w[6 * i + 5]); }
+          unsigned long long tl = 0, tr = 0, tt = 0; for (int i = 0; i < 4096; ++i) { tl += w[6 * i]; tr += w[6 * i + 2]; tt += w[6 * i + 3]; }
+          fprintf(stderr, "[qd profile] all waves: life %llu ticks, rounds %llu, tasks %llu\n", tl, tr, tt); }
         fprintf(stderr, "[qd profile] timeline (ticks since first wave start): first pool-empty %llu, last pool-empty %llu, last wave end %llu, mean wave life %llu\n",
                 h[19] - h[16], h[18] - h[16], h[17] - h[16], h[20] / 4096);
         fprintf(stderr, "[qd profile] wave-cycles total %llu sched %llu trace %llu shade %llu | kd lane-iters %llu wave-iters %llu | xform %llu mesh %llu analytic %llu bookkeeping %llu\n", h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], h[7], h[6]);
