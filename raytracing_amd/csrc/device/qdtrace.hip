@@ -40,6 +40,14 @@ constexpr int kEntryWords = 11;
 #endif
 constexpr int kUnitSide = QD_UNIT_SIDE;                  // work unit = kUnitSide x kUnitSide pixels, handed to one wave
 constexpr uint32_t kUnitPx = kUnitSide * kUnitSide;
+#ifndef QD_BUSY_LANES
+#define QD_BUSY_LANES 48
+#endif
+#ifndef QD_BUSY_WINDOWS
+#define QD_BUSY_WINDOWS 3
+#endif
+constexpr uint32_t kBusyWindows = QD_BUSY_WINDOWS;
+constexpr uint32_t kBusyLanes = QD_BUSY_LANES;            // tasks per round that count as "all lanes busy" (see 1b in the kernel)
 constexpr uint32_t kCtlStride = 32;                      // control words sit 128 bytes apart: one cache line each, so the waves'
                                                          // atomics on one counter do not queue up behind those on its neighbours
 constexpr uint32_t kFlagShadow = 0x80000000u, kFlagPrimary = 0x40000000u, kDepthMask = 0x00ffffffu;
@@ -65,6 +73,14 @@ struct Params {
     int32_t* hit_node; int32_t* hit_tri; double* hit_dist;
     unsigned long long* stats;    // 8 counters, see qd_stats
     int* error_flag;
+    // passes (see launch()): pass 0 hands out pixels, later passes hand out the ray tasks the pass before left behind
+    int source;                          // 0 = pixel slots, 1 = task list
+    uint32_t grace;                      // rounds a wave may still run once the pass's work is all handed out; then it leaves
+                                         // its queued tasks to the next pass (0xffffffff = run to the end)
+    uint32_t* pass_done;                 // set by the first wave that finds nothing left to hand out; one cache line further:
+                                         // the number of waves of this pass that have left
+    const uint64_t* in_list; const uint32_t* in_count;     // source 1: tasks, word-major (word w of task i at [w * list_cap + i]);
+    uint64_t* out_list; uint32_t* out_count; size_t list_cap;   // eight regions of list_cap / 8 tasks with a count each
 };
 
 struct Task {
@@ -315,12 +331,18 @@ __device__ QD_OUTLINE void eval_leaf_shader(const DScene& S, const Params& P, in
 // (0 = every queue is exhausted) and the first slot.
 QD_DEV uint32_t fetch_slots(const Params& P, uint32_t home, uint32_t want, uint32_t& first) {
     const uint32_t n_slots = P.n_units * kUnitPx;
-    const uint32_t per = ((n_slots + 7u) / 8u + kUnitPx - 1u) / kUnitPx * kUnitPx;      // whole units per queue
+    const uint32_t per = ((n_slots + 7u) / 8u + kUnitPx - 1u) / kUnitPx * kUnitPx;      // pixels: whole units per queue
     for (uint32_t i = 0; i < 8; ++i) {
         const uint32_t qi = (home + i) & 7u;
-        const uint32_t lo = qi * per;
-        if (lo >= n_slots) continue;
-        const uint32_t size = min(per, n_slots - lo);
+        uint32_t lo, size;
+        if (P.source == 0) {
+            lo = qi * per;
+            if (lo >= n_slots) continue;
+            size = min(per, n_slots - lo);
+        } else {                                                                        // tasks: queue qi = region qi of the list
+            lo = qi * (uint32_t)(P.list_cap / 8);
+            size = min(__hip_atomic_load(&P.in_count[qi * kCtlStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), (uint32_t)(P.list_cap / 8));
+        }
         if (__hip_atomic_load(&P.queue_ctr[qi * kCtlStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= size) continue;
         const uint32_t v = atomicAdd(&P.queue_ctr[qi * kCtlStride], want);
         if (v < size) { first = lo + v; return min(want, size - v); }
@@ -406,6 +428,9 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
     const unsigned long long t_begin = QD_STAMP();
 
     bool pool_empty = false;
+    uint32_t rounds_left = P.grace;            // counts down once the pass's work is all handed out
+    uint32_t win_tasks = 0;                    // tasks this wave traced during those rounds
+    uint32_t busy_windows = 0;
     unsigned long long t_pool_empty = 0, dbg_rounds = 0, dbg_tasks = 0, dbg_rounds_after = 0, dbg_tasks_after = 0;   // QD_PROFILE diagnostics
     const uint64_t* wave_base = P.stack + (size_t)blockIdx.x * 64;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
@@ -419,9 +444,17 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
             uint32_t first = 0, got = 0;
             if (lane == 0) got = fetch_slots(P, blockIdx.x & 7u, (uint32_t)__popcll(idle), first);
             got = __shfl(got, 0, 64); first = __shfl(first, 0, 64);
-            if (got == 0u) { pool_empty = true; t_pool_empty = QD_STAMP(); break; }
+            if (got == 0u) {
+                pool_empty = true; t_pool_empty = QD_STAMP();
+                if (lane == 0) __hip_atomic_store(P.pass_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
             const uint32_t rank = __popcll(idle & lanes_below);
-            if (q.sp == 0 && rank < got) {
+            if (q.sp == 0 && rank < got && P.source != 0) {            // a task the pass before left behind
+                const uint64_t* e = P.in_list + (first + rank);
+                for (int w = 0; w < kEntryWords; ++w) q.base[(size_t)w * q.stride] = e[(size_t)w * P.list_cap];
+                q.sp = 1;
+            } else if (q.sp == 0 && rank < got) {
                 const uint32_t slot = first + rank;
                 const PixelSlot px = map_pixel(P, slot / kUnitPx, slot % kUnitPx);
                 if (px.valid) {
@@ -444,6 +477,52 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
             }
             idle = __ballot(q.sp == 0);
         }
+        // 1b. end of the pass.  Work is handed out by pixels, but a pixel on a glass object is a tree of up to thousands of
+        //     rays and all of them stay in the wave that took the pixel: once the pixels are gone a few overloaded waves
+        //     would run on alone (reference scene kdtree_test: one wave 650 rounds, the median wave 9).  So every wave
+        //     -- busy ones included, they look at the flag each round -- runs `grace` more rounds, then appends its
+        //     queued tasks to a list and leaves; the next pass (a new launch of this kernel) deals that list out over
+        //     all the waves, and so on with ever shallower trees.  The last pass runs to the end.
+        if (P.grace != 0xffffffffu) {
+            if (!pool_empty) {
+                uint32_t done = 0;
+                if (lane == 0) done = __hip_atomic_load(P.pass_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__shfl(done, 0, 64) != 0u) pool_empty = true;
+            }
+            if (pool_empty) {
+                if (rounds_left == 0u) {
+                    uint32_t incl = (uint32_t)q.sp;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += v; }
+                    const uint32_t total = __shfl(incl, 63, 64);
+                    // Handing tasks over only pays for a wave that is short of lanes, not of work: one that has kept (nearly)
+                    // all its lanes busy since the pixels ran out.  A wave whose rounds are thin is walking the last
+                    // generations of its ray trees -- a chain of dependencies that another wave could not shorten -- and a
+                    // new pass would only make the tasks wait for this one to end.  It looks again after `grace` rounds.
+                    // ... and only if there is somebody to take them: three quarters of the pass's waves have left already.
+                    uint32_t gone = 0;
+                    if (lane == 0) gone = __hip_atomic_load(P.pass_done + kCtlStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gone = __shfl(gone, 0, 64);
+                    // ... and stays that way: kBusyWindows windows in a row (a wave that is merely finishing the last few
+                    // rounds of its trees is faster alone than through a new pass)
+                    busy_windows = (win_tasks >= kBusyLanes * P.grace && gone * 4u >= gridDim.x * 3u) ? busy_windows + 1u : 0u;
+                    if (busy_windows < kBusyWindows) { rounds_left = P.grace; win_tasks = 0; goto keep_running; }
+                    // one region of the list per XCD label (eight counters, a cache line each); a region holds the full
+                    // queues of all the waves with that label, so it cannot overflow
+                    const uint32_t region = blockIdx.x & 7u;
+                    uint32_t at = 0;
+                    if (lane == 0 && total != 0u) at = atomicAdd(&P.out_count[region * kCtlStride], total);
+                    at = __shfl(at, 0, 64) + region * (uint32_t)(P.list_cap / 8) + incl - (uint32_t)q.sp;
+                    for (int e = 0; e < q.sp; ++e)
+                        for (int w = 0; w < kEntryWords; ++w)
+                            P.out_list[(size_t)w * P.list_cap + at + e] = q.base[((size_t)e * kEntryWords + w) * q.stride];
+                    q.sp = 0;
+                    break;
+                }
+                --rounds_left;
+            }
+        }
+        keep_running:
         // 2. every lane with work takes its newest task
         bool have = q.sp > 0;
         Task t;
@@ -484,6 +563,7 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
             }
         }
         if (__ballot(have) == 0ull) break;         // pool empty and no task left in this wave
+        if (pool_empty) win_tasks += (uint32_t)__popcll(__ballot(have));
 #ifdef QD_PROFILE
         { const unsigned long long n = (unsigned long long)__popcll(__ballot(have));
           dbg_rounds += 1; dbg_tasks += n; if (pool_empty) { dbg_rounds_after += 1; dbg_tasks_after += n; } }
@@ -538,6 +618,7 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
         } while (false);
         add_px(P, t.pixel, acc);
     }
+    if (lane == 0 && P.grace != 0xffffffffu) atomicAdd(P.pass_done + kCtlStride, 1u);     // this wave has left the pass
 #ifdef QD_PROFILE
     if (P.stats) { atomicAdd(&P.stats[12], cnt.t_desc); atomicAdd(&P.stats[13], cnt.t_leaf); }   // lane / wave iterations of the KD loop
     if (P.stats && lane == 0) {   // diagnostic build: wave-cycle shares go to their own words, never into outputs
@@ -557,10 +638,10 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
         uint32_t a = 0, b = 0, c = 0;
         if (STATS) { a = wave_sum(cnt.kd_nodes); b = wave_sum(cnt.tris); c = wave_sum(cnt.mesh_queries); }
         if (lane == 0) {
-            atomicAdd(&P.stats[0], (unsigned long long)r + s);
-            atomicAdd(&P.stats[1], (unsigned long long)p);
-            atomicAdd(&P.stats[2], (unsigned long long)s);
-            atomicAdd(&P.stats[3], (unsigned long long)k);
+            if (r + s) atomicAdd(&P.stats[0], (unsigned long long)r + s);
+            if (p) atomicAdd(&P.stats[1], (unsigned long long)p);
+            if (s) atomicAdd(&P.stats[2], (unsigned long long)s);
+            if (k) atomicAdd(&P.stats[3], (unsigned long long)k);
             if (STATS) {
                 atomicAdd(&P.stats[4], (unsigned long long)a);
                 atomicAdd(&P.stats[5], (unsigned long long)b);
@@ -709,7 +790,9 @@ struct qd_scene {
     uint32_t stack_cap = 0;
     uint32_t n_lanes = 0;
     uint64_t* stack = nullptr;
-    uint32_t* queue_ctr = nullptr;       // 8 work-queue counters, one cache line each (kCtlStride words apart)
+    uint32_t* queue_ctr = nullptr;       // per pass: 8 work-queue counters, 8 list counts, done flag, one cache line each
+    uint64_t* lists[2] = {nullptr, nullptr};   // task lists handed from pass to pass (ping-pong), each as large as all the queues
+    size_t list_cap = 0;
     unsigned long long* stats = nullptr; // 8 counters
     int* error_flag = nullptr;
     uint32_t spawn0 = 1, spawn1 = 1;     // tasks queued per hit at depth 0 / deeper
@@ -739,19 +822,53 @@ int ensure_stack(qd_scene* s, uint32_t max_depth) {
     if (s->stack) { (void)hipFree(s->stack); s->stack = nullptr; }
     HIP_TRY(hipMalloc((void**)&s->stack, (size_t)cap * kEntryWords * 8 * s->n_lanes));
     s->stack_cap = cap;
+    for (int i = 0; i < 2; ++i) {                 // a list can take every queue filled to the brim: it cannot overflow
+        if (s->lists[i]) { (void)hipFree(s->lists[i]); s->lists[i] = nullptr; }
+        HIP_TRY(hipMalloc((void**)&s->lists[i], (size_t)cap * kEntryWords * 8 * s->n_lanes));
+    }
+    s->list_cap = (size_t)cap * s->n_lanes;
     return 0;
 }
 
+// One frame (or rectangle, or sample list) = kPasses launches of the trace kernel on the stream: pass 0 hands out pixels,
+// each later pass hands out the ray tasks the pass before left in its list (see 1b in the kernel), the last pass runs
+// to the end.  A pass that finds an empty list is one launch of waves that leave at once (~20 us).
+#ifndef QD_PASSES
+#define QD_PASSES 3
+#endif
+#ifndef QD_GRACE
+#define QD_GRACE 4
+#endif
+#ifndef QD_LATER_DIV
+#define QD_LATER_DIV 2
+#endif
+constexpr uint32_t kLaterPassDiv = QD_LATER_DIV;
+constexpr int kPasses = QD_PASSES;
+constexpr uint32_t kGrace = QD_GRACE;
+constexpr uint32_t kPassWords = 18 * kCtlStride;   // control words per pass, one cache line each: 8 work-queue counters, 8 list counts,
+                                                   // done flag, count of waves that have left
+
 int launch(qd_scene* s, Params& P, hipStream_t stream) {
-    P.queue_ctr = s->queue_ctr; P.stack = s->stack; P.stack_cap = s->stack_cap; P.n_lanes = s->n_lanes;
+    P.stack = s->stack; P.stack_cap = s->stack_cap; P.n_lanes = s->n_lanes;
     P.error_flag = s->error_flag;
-    HIP_TRY(hipMemsetAsync(s->queue_ctr, 0, 8 * kCtlStride * sizeof(uint32_t), stream));
+    P.list_cap = s->list_cap;
+    HIP_TRY(hipMemsetAsync(s->queue_ctr, 0, (size_t)kPasses * kPassWords * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));       // the kernel adds colours into it
     const uint32_t max_blocks = s->n_lanes / 64;
-    const uint32_t grid = P.n_units < max_blocks ? (P.n_units ? P.n_units : 1) : max_blocks;
-    if (g_counting) hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(64), 0, stream, s->d, P);
-    else hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(64), 0, stream, s->d, P);
-    HIP_TRY(hipGetLastError());
+    for (int pass = 0; pass < kPasses; ++pass) {
+        uint32_t* ctl = s->queue_ctr + (size_t)pass * kPassWords;
+        P.queue_ctr = ctl; P.out_count = ctl + 8 * kCtlStride; P.pass_done = ctl + 16 * kCtlStride;
+        P.source = pass == 0 ? 0 : 1;
+        P.in_count = pass == 0 ? nullptr : ctl - kPassWords + 8 * kCtlStride;
+        P.in_list = pass == 0 ? nullptr : s->lists[(pass - 1) & 1];
+        P.out_list = s->lists[pass & 1];
+        P.grace = pass == kPasses - 1 ? 0xffffffffu : kGrace;
+        // later passes usually find an empty list; a launch costs ~45 ns per wave (scratch set-up), so they start fewer waves
+        const uint32_t grid = pass == 0 ? (P.n_units < max_blocks ? (P.n_units ? P.n_units : 1) : max_blocks) : (max_blocks + kLaterPassDiv - 1) / kLaterPassDiv;
+        if (g_counting) hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(64), 0, stream, s->d, P);
+        else hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(64), 0, stream, s->d, P);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
@@ -949,7 +1066,7 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     for (int f = 0; f < 6; ++f) d.env_faces[f] = desc->env_faces[f];
     s->spawn0 = spawn0; s->spawn1 = spawn1;
     s->n_lanes = (uint32_t)(g_num_cu > 0 ? g_num_cu : 256) * kWavesPerCU * 64u;
-    if (!rc && hipMalloc((void**)&s->queue_ctr, 8 * kCtlStride * sizeof(uint32_t)) != hipSuccess) rc = set_err("hipMalloc(queue counters) failed");
+    if (!rc && hipMalloc((void**)&s->queue_ctr, (size_t)kPasses * kPassWords * sizeof(uint32_t)) != hipSuccess) rc = set_err("hipMalloc(queue counters) failed");
     if (!rc && hipMalloc((void**)&s->stats, (24 + 6 * 4096) * sizeof(unsigned long long)) != hipSuccess) rc = set_err("hipMalloc(stats) failed");
     if (!rc && hipMalloc((void**)&s->error_flag, sizeof(int)) != hipSuccess) rc = set_err("hipMalloc(error flag) failed");
     if (!rc && hipMemset(s->error_flag, 0, sizeof(int)) != hipSuccess) rc = set_err("hipMemset failed");
@@ -964,6 +1081,7 @@ extern "C" void qd_scene_destroy(qd_scene* s) {
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->stack) (void)hipFree(s->stack);
     if (s->queue_ctr) (void)hipFree(s->queue_ctr);
+    for (int i = 0; i < 2; ++i) if (s->lists[i]) (void)hipFree(s->lists[i]);
     if (s->stats) (void)hipFree(s->stats);
     if (s->error_flag) (void)hipFree(s->error_flag);
     delete s;
