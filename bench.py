@@ -110,7 +110,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        fr.render_frame()
+        fr.render_frame(antialias=False)
     barrier()
     fr.check()
 
@@ -166,7 +166,9 @@ def main():
                        "parallelism": f"tiles{args.tile}x{args.tile} interleaved over {world} rank(s), RCCL gather to rank 0"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "trace_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": "trace_kernel", "kernel_ms": kernel_ms, "launches_per_step": 3,
+                         "note": "one frame = 3 launches of trace_kernel (pixels, then two passes over handed-over ray tasks, usually empty); kernel_ms, achieved and traffic are per frame = the sum over the three (rocprofv3: TotalDurationNs / frames)",
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "kd_nodes_visited": cstats["kd_nodes_visited"], "tris_tested": cstats["tris_tested"]},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -256,6 +256,12 @@ int qd_render(qd_scene* scene, const qd_camera* camera, const qd_settings* setti
 int qd_antialias(qd_scene* scene, const qd_camera* camera, const qd_settings* settings,
                  float* rgb, size_t row_pitch_floats, qd_stats* stats);
 
+/* Same pass on a frame that is already in DEVICE memory (contiguous frame_width x frame_height x 3 floats, e.g.
+ * the frame qd_untile_async assembled on rank 0), in place.  Synchronous: the mark / replace rule needs two small
+ * read-backs.  Work queued on other streams for the same buffer must have finished. */
+int qd_antialias_device(qd_scene* scene, const qd_camera* camera, const qd_settings* settings,
+                        float* rgb_dev, qd_stats* stats);
+
 /* Same as qd_render but every output pointer is DEVICE memory and the call only
  * enqueues work on `hip_stream` (a hipStream_t passed as void*; NULL = default
  * stream).  Pixels are selected by tile ownership instead of a rectangle:

@@ -1162,11 +1162,13 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
 }
 
 
-extern "C" int qd_antialias(qd_scene* s, const qd_camera* cam, const qd_settings* st, float* rgb, size_t pitch, qd_stats* stats) {
-    if (!s || !cam || !st || !rgb) return set_err("qd_antialias: null argument");
+namespace {
+// rgb: host buffer with `pitch`, or (rgb_dev) a contiguous W x H x 3 device buffer; in place either way
+int antialias_impl(qd_scene* s, const qd_camera* cam, const qd_settings* st, float* rgb, size_t pitch, float* rgb_dev, qd_stats* stats) {
+    if (!s || !cam || !st || !(rgb || rgb_dev)) return set_err("qd_antialias: null argument");
     const int W = st->frame_width, H = st->frame_height;
     if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return set_err("qd_antialias: frame size out of range");
-    if (pitch < (size_t)W * 3) return set_err("qd_antialias: row pitch smaller than the frame");
+    if (!rgb_dev && pitch < (size_t)W * 3) return set_err("qd_antialias: row pitch smaller than the frame");
     if (ensure_stack(s, st->max_trace_depth)) return -1;
     const size_t npx = (size_t)W * H;
     float *d_first = nullptr, *d_a = nullptr, *d_b = nullptr, *d_taps = nullptr, *d_aa = nullptr;
@@ -1185,7 +1187,8 @@ extern "C" int qd_antialias(qd_scene* s, const qd_camera* cam, const qd_settings
     TRY2(hipMalloc((void**)&d_list, npx * sizeof(uint32_t)));
     TRY2(hipMalloc((void**)&d_count, sizeof(uint32_t)));
     TRY2(hipMalloc((void**)&d_changed, sizeof(int)));
-    TRY2(hipMemcpy2D(d_first, (size_t)W * 3 * sizeof(float), rgb, pitch * sizeof(float), (size_t)W * 3 * sizeof(float), H, hipMemcpyHostToDevice));
+    if (rgb_dev) TRY2(hipMemcpy(d_first, rgb_dev, npx * 3 * sizeof(float), hipMemcpyDeviceToDevice));
+    else TRY2(hipMemcpy2D(d_first, (size_t)W * 3 * sizeof(float), rgb, pitch * sizeof(float), (size_t)W * 3 * sizeof(float), H, hipMemcpyHostToDevice));
     TRY2(hipMemset(d_count, 0, sizeof(uint32_t)));
     TRY2(hipMemsetAsync(s->stats, 0, 24 * sizeof(unsigned long long), nullptr));
     TRY2(hipMemsetAsync(s->stats + 16, 0xff, sizeof(unsigned long long), nullptr)); TRY2(hipMemsetAsync(s->stats + 19, 0xff, sizeof(unsigned long long), nullptr));
@@ -1229,7 +1232,8 @@ extern "C" int qd_antialias(qd_scene* s, const qd_camera* cam, const qd_settings
     int err_flag = 0;
     TRY2(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
     if (err_flag) { cleanup(); return set_err(err_flag == 2 ? "qd_antialias: marked pixel outside the traced set" : "qd_antialias: ray queue overflow on device"); }
-    TRY2(hipMemcpy2D(rgb, pitch * sizeof(float), cur, (size_t)W * 3 * sizeof(float), (size_t)W * 3 * sizeof(float), H, hipMemcpyDeviceToHost));
+    if (rgb_dev) TRY2(hipMemcpy(rgb_dev, cur, npx * 3 * sizeof(float), hipMemcpyDeviceToDevice));
+    else TRY2(hipMemcpy2D(rgb, pitch * sizeof(float), cur, (size_t)W * 3 * sizeof(float), (size_t)W * 3 * sizeof(float), H, hipMemcpyDeviceToHost));
     if (stats) {
         unsigned long long h[16];
         TRY2(hipMemcpy(h, s->stats, sizeof h, hipMemcpyDeviceToHost));
@@ -1240,6 +1244,17 @@ extern "C" int qd_antialias(qd_scene* s, const qd_camera* cam, const qd_settings
     cleanup();
 #undef TRY2
     return 0;
+}
+}  // namespace
+
+extern "C" int qd_antialias(qd_scene* s, const qd_camera* cam, const qd_settings* st, float* rgb, size_t pitch, qd_stats* stats) {
+    if (!rgb) return set_err("qd_antialias: null argument");
+    return antialias_impl(s, cam, st, rgb, pitch, nullptr, stats);
+}
+
+extern "C" int qd_antialias_device(qd_scene* s, const qd_camera* cam, const qd_settings* st, float* rgb_dev, qd_stats* stats) {
+    if (!rgb_dev) return set_err("qd_antialias_device: null argument");
+    return antialias_impl(s, cam, st, nullptr, 0, rgb_dev, stats);
 }
 
 extern "C" int qd_render_tiles_async(qd_scene* s, const qd_camera* cam, const qd_settings* st, int tile, int tile_phase,

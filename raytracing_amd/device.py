@@ -32,6 +32,7 @@ def lib():
         L.qd_render.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, P(abi.QdStats)]
         L.qd_antialias.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_void_p, C.c_size_t, P(abi.QdStats)]
+        L.qd_antialias_device.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_void_p, P(abi.QdStats)]
         L.qd_render_tiles_async.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p]
         L.qd_untile_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -100,6 +101,14 @@ class DeviceScene:
             raise DeviceError("antialias: rgb must be C-contiguous float32[frame_height, frame_width, 3]")
         stats = abi.QdStats()
         _check(lib().qd_antialias(self._h, C.byref(cam), C.byref(st), rgb.ctypes.data, st.frame_width * 3, C.byref(stats)), "qd_antialias")
+        return stats.as_dict()
+
+    def antialias_device(self, rgb_dev_ptr, camera=None, settings=None):
+        """The AA pass on a contiguous W x H x 3 float frame in device memory, in place (synchronous)."""
+        st = settings if settings is not None else self.host_scene.settings
+        cam = camera if camera is not None else self.host_scene.camera
+        stats = abi.QdStats()
+        _check(lib().qd_antialias_device(self._h, C.byref(cam), C.byref(st), C.c_void_p(rgb_dev_ptr), C.byref(stats)), "qd_antialias_device")
         return stats.as_dict()
 
     def render_frame(self, camera=None, settings=None):

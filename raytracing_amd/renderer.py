@@ -49,9 +49,16 @@ class FrameRenderer:
                             stream=stream)
         return self.frame
 
-    def render_frame(self):
+    def render_frame(self, antialias=None):
+        """RenderScene: every rank traces its tiles, rank 0 gathers; if settings.wantAA (or antialias=True) rank 0 then
+        runs the AA pass on the assembled frame (src/main.cpp:106-153 needs the whole first pass)."""
         self.render_shard()
-        return self.gather()
+        frame = self.gather()
+        want = self.scene.settings.want_aa if antialias is None else antialias
+        if want and frame is not None:
+            torch.cuda.current_stream(self.dev).synchronize()
+            self.dscene.antialias_device(frame.data_ptr())
+        return frame
 
     def stats_dict(self):
         v = self.stats.cpu().tolist()

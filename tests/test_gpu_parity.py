@@ -225,3 +225,56 @@ def test_full_aa_and_bucket_border_dependency(load_scene):
         assert st["primary_rays"] == 5 * n
     finally:
         _aa_settings(s, **old)
+
+
+# ---------------------------------------------------------------- device KD tree options
+def test_callers_tree_and_refined_tree_give_the_same_hits(load_scene):
+    """qd_set_kd_refine(0, .) walks the caller's leaves (up to 19 triangles each), the default splits them further:
+    same closest hits bit for bit, far fewer triangle tests."""
+    s = load_scene("kdtree_fixed.qdmg")
+    s.settings.want_aa = 0
+    out = {}
+    try:
+        for max_leaf in (0, 2):
+            device.set_kd_refine(max_leaf, 0.6)
+            ds = device.DeviceScene(s)
+            try:
+                device.set_counting(True)
+                rgb, (hn, ht, hd), st = ds.render(400, 300, 800, 600, hits=True)
+                out[max_leaf] = (rgb, hn, ht, hd, st, ds.kd_info())
+            finally:
+                device.set_counting(False)
+                ds.close()
+    finally:
+        device.set_kd_refine(2, 0.6)
+    (rgb0, hn0, ht0, hd0, st0, info0), (rgb2, hn2, ht2, hd2, st2, info2) = out[0], out[2]
+    assert (ht0 >= 0).sum() > 1000                       # the mesh is really in view
+    assert np.array_equal(hn0, hn2) and np.array_equal(ht0, ht2)
+    assert np.array_equal(hd0.view(np.uint64), hd2.view(np.uint64))
+    assert np.abs(rgb0 - rgb2).max() <= SUM_ORDER_TOL
+    assert info0["leaf_refs"] == round(s.kd_stats(0)["avg_tris"] * s.kd_stats(0)["leaves"]) and info0["max_leaf"] <= 20
+    assert info2["nodes"] > info0["nodes"] and st2["tris_tested"] * 1.5 < st0["tris_tested"], (info0, info2, st0["tris_tested"], st2["tris_tested"])
+
+
+def test_frame_renderer_runs_the_aa_pass_on_the_gathered_frame(load_scene):
+    """FrameRenderer.render_frame with wantAA: tiles -> untile -> qd_antialias_device == qd_render + qd_antialias."""
+    from raytracing_amd import renderer
+    s = load_scene("hw9/nonconvex.qdmg")
+    old = _aa_settings(s, want_aa=1, want_adaptive_aa=1, show_aa=0)
+    try:
+        fr = renderer.FrameRenderer(s, tile=32, rank=0, world=1, local_device=0)
+        try:
+            frame = fr.render_frame().cpu().numpy()
+            fr.check()
+        finally:
+            fr.dscene.close()
+        ds = device.DeviceScene(s)
+        try:
+            ref, _ = ds.render_frame()
+        finally:
+            ds.close()
+    finally:
+        _aa_settings(s, **old)
+    assert np.abs(frame - ref).max() <= SUM_ORDER_TOL
+    first, _, _ = device.DeviceScene(s).render()
+    assert np.abs(frame - first).max() > 1e-3        # the pass changed something
