@@ -22,7 +22,8 @@ for f in glob.glob(out + "/*/*/*counter_collection.csv"):
         k = row["Kernel_Name"]
         if "trace_kernel<false>" not in k: continue
         res[row["Counter_Name"]].setdefault("vals", []).append(float(row["Counter_Value"]))
-summary = {c: sum(v["vals"]) / len(v["vals"]) for c, v in res.items()}
+LAUNCHES_PER_FRAME = 3   # one frame = 3 launches of trace_kernel (launch() in qdtrace.hip); counters are summed per frame
+summary = {c: sum(v["vals"]) / (len(v["vals"]) / LAUNCHES_PER_FRAME) for c, v in res.items()}
 json.dump(summary, open(out + "/pmc_summary.json", "w"), indent=1)
 print(json.dumps(summary, indent=1))
 PY
