@@ -3,7 +3,9 @@
 
 A "step" is one full frame of the workload: every rank traces its interleaved tile set with the HIP
 kernels (scene buffers replicated per GPU, already resident in HBM), the compacted shards are
-gathered to rank 0 over RCCL and de-interleaved.  `value` is whole-job rays/s, where a ray is a
+gathered to rank 0 over RCCL and de-interleaved.  Up to --frames-in-flight frames are in flight at a time,
+each on its own HIP stream with its own buffers (the thin tail of one frame overlaps the start of the next);
+all K frames are complete when the clock stops.  `value` is whole-job rays/s, where a ray is a
 traced Raytrace call (src/main.cpp:20) or a shadow query (src/shadinghelper.cpp:20), counted on
 the device.
 
@@ -74,6 +76,8 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames enqueued at a time, one HIP stream each (1 = strictly one after the other; 0 = by shard size: 2 at 1 GPU, 3 at 2, 4 beyond)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kd-refine", default=None, help="'max_leaf,step_cost' for qd_set_kd_refine (tuning; default = library default)")
     args = ap.parse_args()
@@ -97,11 +101,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
+    if args.frames_in_flight == 0:
+        # frames needed to keep the chip full ~ critical path of a frame (4-5 ms of dependent ray generations) / work per shard
+        args.frames_in_flight = 2 if world == 1 else 3 if world == 2 else 4
     if args.kd_refine:
         ml, sc = args.kd_refine.split(",")
         device.set_kd_refine(int(ml), float(sc))
     scene, workload = build_scene(args)
-    fr = renderer.FrameRenderer(scene, tile=args.tile, rank=rank, world=world, local_device=local)
+    fr = renderer.FrameRenderer(scene, tile=args.tile, rank=rank, world=world, local_device=local,
+                                frames_in_flight=args.frames_in_flight)
     W, H = fr.W, fr.H
 
     def barrier():
@@ -110,22 +118,28 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        fr.render_frame(antialias=False)
+        fr.submit_frame()
     barrier()
     fr.check()
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record()
-        fr.render_shard()          # the dominant kernel, on torch's current stream
-        ev[i][1].record()
-        fr.gather()
-    barrier()
+        fr.submit_frame()          # trace + gather + de-interleave of one frame, on the stream of slot i % F
+    barrier()                      # torch.cuda.synchronize() waits for every stream: all K frames are complete here
     elapsed = time.perf_counter() - t0
     fr.check()
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+
+    # roofline leg, untimed: the dominant kernel alone, launches strictly one after the other on torch's current
+    # stream with HIP events around each frame's launches (overlapped launches would stretch each other's duration)
+    n_roof = max(3, min(args.steps, 10))
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_roof)]
+    for a, b in ev:
+        a.record()
+        fr.render_shard()
+        b.record()
+    torch.cuda.synchronize()
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / n_roof
 
     stats = fr.stats_dict()
     rays_local = torch.tensor([stats["rays"], stats["primary_rays"], stats["shadow_rays"]], dtype=torch.float64, device=fr.dev)
@@ -163,11 +177,12 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "width": W, "height": H, "rays_per_frame": int(rays_frame),
                        "primary_rays": int(rays_local[1].item()), "shadow_rays": int(rays_local[2].item()),
-                       "parallelism": f"tiles{args.tile}x{args.tile} interleaved over {world} rank(s), RCCL gather to rank 0"},
+                       "parallelism": f"tiles{args.tile}x{args.tile} interleaved over {world} rank(s), RCCL gather to rank 0",
+                       "frames_in_flight": args.frames_in_flight},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "trace_kernel", "kernel_ms": kernel_ms, "launches_per_step": 3,
-                         "note": "one frame = 3 launches of trace_kernel (pixels, then two passes over handed-over ray tasks, usually empty); kernel_ms, achieved and traffic are per frame = the sum over the three (rocprofv3: TotalDurationNs / frames)",
+                         "note": "one frame = 3 launches of trace_kernel (pixels, then two passes over handed-over ray tasks, usually empty); kernel_ms, achieved and traffic are per frame = the sum over the three, measured on launches that run alone (a separate untimed loop after the timed region; rocprofv3 of `bench.py --frames-in-flight 1`: TotalDurationNs / frames); the timed region overlaps frames, so ms_per_step can be below kernel_ms",
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kd_nodes_visited": cstats["kd_nodes_visited"], "tris_tested": cstats["tris_tested"]},
         }

@@ -269,10 +269,20 @@ int qd_antialias_device(qd_scene* scene, const qd_camera* camera, const qd_setti
  * the tiles t with t % tile_stride == tile_phase (multi-GPU sharding,
  * one process per GPU) and writes them *compacted*: owned tile number k (in
  * increasing t) occupies rgb_dev[k*tile*tile*3 ...], row-major inside the tile.
- * Used by bench.py / the RCCL gather path.  stats_dev: optional device qd_stats. */
+ * Used by bench.py / the RCCL gather path.  stats_dev: optional device qd_stats.
+ * Frames in flight: a scene keeps up to 4 working sets (ray queues, task lists, control words),
+ * each bound to the stream that used it last.  Calls on ONE stream share a set and run in order;
+ * calls on DIFFERENT streams use different sets and may overlap on the GPU (the thin tail of one
+ * frame runs beside the start of the next) -- give each such call its own rgb_dev / stats_dev.  A fifth
+ * stream takes over the set used longest ago and first waits, on the device, for that set's last launch. */
 int qd_render_tiles_async(qd_scene* scene, const qd_camera* camera, const qd_settings* settings,
                           int tile, int tile_phase, int tile_stride,
                           float* rgb_dev, qd_stats* stats_dev, void* hip_stream);
+
+/* Replaces: nothing in the reference (it renders one frame at a time on one thread, src/main.cpp:163-168).
+ * Binds a working set of the scene to `hip_stream` and sizes it for max_trace_depth now, so that later
+ * qd_render_tiles_async calls on that stream allocate nothing (see "Frames in flight" above). */
+int qd_scene_bind_stream(qd_scene* scene, int max_trace_depth, void* hip_stream);
 
 /* De-interleave kernel for the gathered framebuffer: src_dev holds, for each rank r in
  * [0, tile_stride), that rank's compacted tiles (each rank's block padded to

@@ -784,15 +784,29 @@ int set_err(const std::string& m) { g_err = m; return -1; }
 
 }  // namespace
 
+// Working memory of one frame in flight: the per-lane ray queues, the two task lists handed from pass to pass and the
+// control words.  A scene holds up to kMaxWorkSets of them, each bound to the HIP stream that used it last, so frames
+// rendered on different streams overlap on the GPU: the tail of one frame (few waves walking the last generations of
+// their ray trees) runs beside the start of the next.  Launches on one stream share a set and serialise as before.
+constexpr int kMaxWorkSets = 4;              // = hardware queues a process gets on this pool (GPU_MAX_HW_QUEUES)
+struct WorkSet {
+    bool bound = false;
+    hipStream_t stream = nullptr;
+    uint32_t stack_cap = 0;
+    uint64_t* stack = nullptr;
+    uint32_t* queue_ctr = nullptr;           // per pass: 8 work-queue counters, 8 list counts, done flag, one cache line each
+    uint64_t* lists[2] = {nullptr, nullptr}; // task lists handed from pass to pass (ping-pong), each as large as all the queues
+    size_t list_cap = 0;
+    hipEvent_t idle = nullptr;               // recorded behind the set's last launch; a stream that takes the set over waits on it
+    uint64_t last_use = 0;
+};
+
 struct qd_scene {
     DScene d;
     std::vector<void*> allocs;
-    uint32_t stack_cap = 0;
     uint32_t n_lanes = 0;
-    uint64_t* stack = nullptr;
-    uint32_t* queue_ctr = nullptr;       // per pass: 8 work-queue counters, 8 list counts, done flag, one cache line each
-    uint64_t* lists[2] = {nullptr, nullptr};   // task lists handed from pass to pass (ping-pong), each as large as all the queues
-    size_t list_cap = 0;
+    WorkSet sets[kMaxWorkSets];
+    uint64_t use_clock = 0;
     unsigned long long* stats = nullptr; // 8 counters
     int* error_flag = nullptr;
     uint32_t spawn0 = 1, spawn1 = 1;     // tasks queued per hit at depth 0 / deeper
@@ -813,29 +827,57 @@ int upload(qd_scene* s, const T* src, size_t n, const T** dst) {
     return 0;
 }
 
-int ensure_stack(qd_scene* s, uint32_t max_depth) {
+constexpr uint32_t kPassWords = 18 * kCtlStride;   // control words per pass, one cache line each: 8 work-queue counters, 8 list counts,
+                                                   // done flag, count of waves that have left
+#ifndef QD_PASSES
+#define QD_PASSES 3
+#endif
+constexpr int kPasses = QD_PASSES;
+
+void free_set(WorkSet& w) {
+    if (w.stack) (void)hipFree(w.stack);
+    if (w.queue_ctr) (void)hipFree(w.queue_ctr);
+    for (int i = 0; i < 2; ++i) if (w.lists[i]) (void)hipFree(w.lists[i]);
+    if (w.idle) (void)hipEventDestroy(w.idle);
+    w = WorkSet();
+}
+
+// The working set for a launch on `stream`, sized for max_depth: the set the stream used before, else a free one, else
+// the one used longest ago (the stream then waits for that set's last launch).  Allocates only when a set is new or
+// too small; qd_scene_bind_stream does this ahead of time.
+int acquire_set(qd_scene* s, hipStream_t stream, uint32_t max_depth, WorkSet** out) {
     // LIFO bound: each processed task removes one slot and adds at most spawn tasks.
     const uint64_t cap64 = (uint64_t)s->spawn0 + (uint64_t)s->spawn1 * max_depth + 2;
     if (cap64 > 4096) return set_err("ray queue bound too large for this scene (samples x depth)");
     const uint32_t cap = (uint32_t)cap64;
-    if (s->stack && cap <= s->stack_cap) return 0;
-    if (s->stack) { (void)hipFree(s->stack); s->stack = nullptr; }
-    HIP_TRY(hipMalloc((void**)&s->stack, (size_t)cap * kEntryWords * 8 * s->n_lanes));
-    s->stack_cap = cap;
-    for (int i = 0; i < 2; ++i) {                 // a list can take every queue filled to the brim: it cannot overflow
-        if (s->lists[i]) { (void)hipFree(s->lists[i]); s->lists[i] = nullptr; }
-        HIP_TRY(hipMalloc((void**)&s->lists[i], (size_t)cap * kEntryWords * 8 * s->n_lanes));
+    WorkSet* w = nullptr;
+    for (auto& c : s->sets) if (c.bound && c.stream == stream) { w = &c; break; }
+    if (!w) for (auto& c : s->sets) if (!c.bound) { w = &c; break; }
+    if (!w) {
+        w = &s->sets[0];
+        for (auto& c : s->sets) if (c.last_use < w->last_use) w = &c;
+        HIP_TRY(hipStreamWaitEvent(stream, w->idle, 0));
     }
-    s->list_cap = (size_t)cap * s->n_lanes;
+    w->bound = true; w->stream = stream; w->last_use = ++s->use_clock;
+    if (!w->idle) HIP_TRY(hipEventCreateWithFlags(&w->idle, hipEventDisableTiming));
+    if (!w->queue_ctr) HIP_TRY(hipMalloc((void**)&w->queue_ctr, (size_t)kPasses * kPassWords * sizeof(uint32_t)));
+    if (!w->stack || cap > w->stack_cap) {
+        if (w->stack) { (void)hipFree(w->stack); w->stack = nullptr; }     // hipFree waits for the device: nothing still reads it
+        HIP_TRY(hipMalloc((void**)&w->stack, (size_t)cap * kEntryWords * 8 * s->n_lanes));
+        w->stack_cap = cap;
+        for (int i = 0; i < 2; ++i) {                 // a list can take every queue filled to the brim: it cannot overflow
+            if (w->lists[i]) { (void)hipFree(w->lists[i]); w->lists[i] = nullptr; }
+            HIP_TRY(hipMalloc((void**)&w->lists[i], (size_t)cap * kEntryWords * 8 * s->n_lanes));
+        }
+        w->list_cap = (size_t)cap * s->n_lanes;
+    }
+    *out = w;
     return 0;
 }
 
 // One frame (or rectangle, or sample list) = kPasses launches of the trace kernel on the stream: pass 0 hands out pixels,
 // each later pass hands out the ray tasks the pass before left in its list (see 1b in the kernel), the last pass runs
 // to the end.  A pass that finds an empty list is one launch of waves that leave at once (~20 us).
-#ifndef QD_PASSES
-#define QD_PASSES 3
-#endif
 #ifndef QD_GRACE
 #define QD_GRACE 4
 #endif
@@ -843,25 +885,24 @@ int ensure_stack(qd_scene* s, uint32_t max_depth) {
 #define QD_LATER_DIV 2
 #endif
 constexpr uint32_t kLaterPassDiv = QD_LATER_DIV;
-constexpr int kPasses = QD_PASSES;
 constexpr uint32_t kGrace = QD_GRACE;
-constexpr uint32_t kPassWords = 18 * kCtlStride;   // control words per pass, one cache line each: 8 work-queue counters, 8 list counts,
-                                                   // done flag, count of waves that have left
 
-int launch(qd_scene* s, Params& P, hipStream_t stream) {
-    P.stack = s->stack; P.stack_cap = s->stack_cap; P.n_lanes = s->n_lanes;
+int launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream) {
+    WorkSet* w = nullptr;
+    if (acquire_set(s, stream, max_depth, &w)) return -1;
+    P.stack = w->stack; P.stack_cap = w->stack_cap; P.n_lanes = s->n_lanes;
     P.error_flag = s->error_flag;
-    P.list_cap = s->list_cap;
-    HIP_TRY(hipMemsetAsync(s->queue_ctr, 0, (size_t)kPasses * kPassWords * sizeof(uint32_t), stream));
+    P.list_cap = w->list_cap;
+    HIP_TRY(hipMemsetAsync(w->queue_ctr, 0, (size_t)kPasses * kPassWords * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));       // the kernel adds colours into it
     const uint32_t max_blocks = s->n_lanes / 64;
     for (int pass = 0; pass < kPasses; ++pass) {
-        uint32_t* ctl = s->queue_ctr + (size_t)pass * kPassWords;
+        uint32_t* ctl = w->queue_ctr + (size_t)pass * kPassWords;
         P.queue_ctr = ctl; P.out_count = ctl + 8 * kCtlStride; P.pass_done = ctl + 16 * kCtlStride;
         P.source = pass == 0 ? 0 : 1;
         P.in_count = pass == 0 ? nullptr : ctl - kPassWords + 8 * kCtlStride;
-        P.in_list = pass == 0 ? nullptr : s->lists[(pass - 1) & 1];
-        P.out_list = s->lists[pass & 1];
+        P.in_list = pass == 0 ? nullptr : w->lists[(pass - 1) & 1];
+        P.out_list = w->lists[pass & 1];
         P.grace = pass == kPasses - 1 ? 0xffffffffu : kGrace;
         // later passes usually find an empty list; a launch costs ~45 ns per wave (scratch set-up), so they start fewer waves
         const uint32_t grid = pass == 0 ? (P.n_units < max_blocks ? (P.n_units ? P.n_units : 1) : max_blocks) : (max_blocks + kLaterPassDiv - 1) / kLaterPassDiv;
@@ -869,6 +910,7 @@ int launch(qd_scene* s, Params& P, hipStream_t stream) {
         else hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(64), 0, stream, s->d, P);
         HIP_TRY(hipGetLastError());
     }
+    HIP_TRY(hipEventRecord(w->idle, stream));
     return 0;
 }
 
@@ -1066,11 +1108,13 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     for (int f = 0; f < 6; ++f) d.env_faces[f] = desc->env_faces[f];
     s->spawn0 = spawn0; s->spawn1 = spawn1;
     s->n_lanes = (uint32_t)(g_num_cu > 0 ? g_num_cu : 256) * kWavesPerCU * 64u;
-    if (!rc && hipMalloc((void**)&s->queue_ctr, (size_t)kPasses * kPassWords * sizeof(uint32_t)) != hipSuccess) rc = set_err("hipMalloc(queue counters) failed");
     if (!rc && hipMalloc((void**)&s->stats, (24 + 6 * 4096) * sizeof(unsigned long long)) != hipSuccess) rc = set_err("hipMalloc(stats) failed");
     if (!rc && hipMalloc((void**)&s->error_flag, sizeof(int)) != hipSuccess) rc = set_err("hipMalloc(error flag) failed");
     if (!rc && hipMemset(s->error_flag, 0, sizeof(int)) != hipSuccess) rc = set_err("hipMemset failed");
-    if (!rc) rc = ensure_stack(s, desc->settings.max_trace_depth);
+    if (!rc) {                                   // working set of the default stream, so that a first render allocates nothing
+        WorkSet* w = nullptr;
+        rc = acquire_set(s, nullptr, desc->settings.max_trace_depth, &w);
+    }
     if (rc) { qd_scene_destroy(s); return -1; }
     *out = s;
     return 0;
@@ -1079,9 +1123,7 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
 extern "C" void qd_scene_destroy(qd_scene* s) {
     if (!s) return;
     for (void* p : s->allocs) (void)hipFree(p);
-    if (s->stack) (void)hipFree(s->stack);
-    if (s->queue_ctr) (void)hipFree(s->queue_ctr);
-    for (int i = 0; i < 2; ++i) if (s->lists[i]) (void)hipFree(s->lists[i]);
+    for (auto& w : s->sets) free_set(w);
     if (s->stats) (void)hipFree(s->stats);
     if (s->error_flag) (void)hipFree(s->error_flag);
     delete s;
@@ -1094,7 +1136,6 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
     if ((hit_node || hit_tri || hit_dist) && !(hit_node && hit_tri && hit_dist)) return set_err("qd_render: hit outputs must be all set or all NULL");
     const int rw = x1 - x0, rh = y1 - y0;
     if (pitch < (size_t)rw * 3) return set_err("qd_render: row pitch smaller than the rectangle");
-    if (ensure_stack(s, st->max_trace_depth)) return -1;
     Params P; fill_common(P, cam, st);
     P.mode = 0; P.x0 = x0; P.y0 = y0; P.rw = rw; P.rh = rh;
     P.units_x = (uint32_t)(rw + kUnitSide - 1) / kUnitSide;
@@ -1121,7 +1162,7 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
     TRY2(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
     TRY2(hipEventCreate(&e0)); TRY2(hipEventCreate(&e1));
     TRY2(hipEventRecord(e0, nullptr));
-    rc = launch(s, P, nullptr);
+    rc = launch(s, P, st->max_trace_depth, nullptr);
     if (rc) { cleanup(); return -1; }
     TRY2(hipEventRecord(e1, nullptr));
     TRY2(hipEventSynchronize(e1));
@@ -1169,7 +1210,6 @@ int antialias_impl(qd_scene* s, const qd_camera* cam, const qd_settings* st, flo
     const int W = st->frame_width, H = st->frame_height;
     if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return set_err("qd_antialias: frame size out of range");
     if (!rgb_dev && pitch < (size_t)W * 3) return set_err("qd_antialias: row pitch smaller than the frame");
-    if (ensure_stack(s, st->max_trace_depth)) return -1;
     const size_t npx = (size_t)W * H;
     float *d_first = nullptr, *d_a = nullptr, *d_b = nullptr, *d_taps = nullptr, *d_aa = nullptr;
     int32_t* d_slot = nullptr; uint32_t* d_list = nullptr; uint32_t* d_count = nullptr; int* d_changed = nullptr;
@@ -1207,7 +1247,7 @@ int antialias_impl(qd_scene* s, const qd_camera* cam, const qd_settings* st, flo
         P.rgb = d_taps; P.rgb_floats = (size_t)P.n_samples * 3; P.stats = s->stats;
         TRY2(hipEventCreate(&e0)); TRY2(hipEventCreate(&e1));
         TRY2(hipEventRecord(e0, nullptr));
-        if (launch(s, P, nullptr)) { cleanup(); return -1; }
+        if (launch(s, P, st->max_trace_depth, nullptr)) { cleanup(); return -1; }
         TRY2(hipEventRecord(e1, nullptr));
         hipLaunchKernelGGL(aa_combine_kernel, dim3((n_list + 255u) / 256u), dim3(256), 0, nullptr, d_first, d_taps, d_list, n_list, W, d_aa);
         TRY2(hipEventSynchronize(e1));
@@ -1261,7 +1301,6 @@ extern "C" int qd_render_tiles_async(qd_scene* s, const qd_camera* cam, const qd
                                      int tile_stride, float* rgb_dev, qd_stats* stats_dev, void* hip_stream) {
     if (!s || !cam || !st || !rgb_dev) return set_err("qd_render_tiles_async: null argument");
     if (tile < 8 || tile % 8 || tile_stride < 1 || tile_phase < 0 || tile_phase >= tile_stride) return set_err("qd_render_tiles_async: bad tiling");
-    if (ensure_stack(s, st->max_trace_depth)) return -1;
     hipStream_t stream = (hipStream_t)hip_stream;
     Params P; fill_common(P, cam, st);
     P.mode = 1; P.tile = tile; P.phase = tile_phase; P.stride = tile_stride;
@@ -1274,7 +1313,13 @@ extern "C" int qd_render_tiles_async(qd_scene* s, const qd_camera* cam, const qd
     P.stats = (unsigned long long*)stats_dev;   // first 7 fields of qd_stats are the 64-bit counters
     if (stats_dev) HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(qd_stats), stream));
     if (P.n_units == 0) return 0;
-    return launch(s, P, stream);
+    return launch(s, P, st->max_trace_depth, stream);
+}
+
+extern "C" int qd_scene_bind_stream(qd_scene* s, int max_trace_depth, void* hip_stream) {
+    if (!s || max_trace_depth < 0) return set_err("qd_scene_bind_stream: bad argument");
+    WorkSet* w = nullptr;
+    return acquire_set(s, (hipStream_t)hip_stream, (uint32_t)max_trace_depth, &w);
 }
 
 extern "C" int qd_untile_async(const float* src_dev, float* dst_dev, int width, int height, int tile, int tile_stride,

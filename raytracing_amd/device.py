@@ -35,6 +35,7 @@ def lib():
         L.qd_antialias_device.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_void_p, P(abi.QdStats)]
         L.qd_render_tiles_async.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p]
+        L.qd_scene_bind_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.qd_untile_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.qd_quantize_bgr8_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
         L.qd_set_kd_refine.argtypes = [C.c_int, C.c_double]
@@ -128,6 +129,11 @@ class DeviceScene:
         _check(lib().qd_render_tiles_async(self._h, C.byref(cam), C.byref(st), tile, phase, stride,
                                            C.c_void_p(rgb_dev_ptr), C.c_void_p(stats_dev_ptr or 0),
                                            C.c_void_p(stream or 0)), "qd_render_tiles_async")
+
+    def bind_stream(self, stream, max_trace_depth=None):
+        """Reserve a working set of the scene for launches on `stream` (frames in flight: one stream per frame)."""
+        d = self.host_scene.settings.max_trace_depth if max_trace_depth is None else max_trace_depth
+        _check(lib().qd_scene_bind_stream(self._h, d, C.c_void_p(stream or 0)), "qd_scene_bind_stream")
 
     def check(self):
         _check(lib().qd_scene_check(self._h), "qd_scene_check")

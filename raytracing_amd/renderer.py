@@ -10,8 +10,27 @@ import torch
 from . import abi, device, sharding
 
 
+class _Slot:
+    """Buffers of one frame in flight."""
+
+    def __init__(self, fr, stream):
+        dev, tile, world = fr.dev, fr.tile, fr.world
+        self.stream = stream                                   # None: whatever stream is current at the call
+        self.shard = torch.zeros((fr.tpr, tile, tile, 3), dtype=torch.float32, device=dev)
+        self.stats = torch.zeros(8, dtype=torch.int64, device=dev)   # qd_stats: 7 counters + kernel_ms slot
+        self.frame = torch.zeros((fr.H, fr.W, 3), dtype=torch.float32, device=dev) if fr.rank == 0 else None
+        self.gathered = (torch.zeros((world, fr.tpr, tile, tile, 3), dtype=torch.float32, device=dev)
+                         if (fr.rank == 0 and world > 1) else None)
+
+
 class FrameRenderer:
-    def __init__(self, scene, tile=32, rank=0, world=1, local_device=0):
+    """frames_in_flight = F > 1: submit_frame() rotates over F slots, each with its own HIP stream, buffers and
+    (inside the library, qd_scene_bind_stream) working set, so that consecutive frames overlap on the GPU: a frame's
+    last ray generations keep only a few waves busy and the next frame's pixels fill the rest of the chip."""
+
+    def __init__(self, scene, tile=32, rank=0, world=1, local_device=0, frames_in_flight=1):
+        if not 1 <= frames_in_flight <= 4:
+            raise ValueError("frames_in_flight must be 1..4 (working sets per scene in libqdtrace)")
         self.scene, self.tile, self.rank, self.world = scene, tile, rank, world
         self.dev = torch.device("cuda", local_device)
         torch.cuda.set_device(self.dev)
@@ -20,34 +39,63 @@ class FrameRenderer:
         st = scene.settings
         self.W, self.H = st.frame_width, st.frame_height
         self.tpr = sharding.tiles_per_rank_padded(self.W, self.H, tile, world)
-        self.shard = torch.zeros((self.tpr, tile, tile, 3), dtype=torch.float32, device=self.dev)
-        self.stats = torch.zeros(8, dtype=torch.int64, device=self.dev)   # qd_stats: 7 counters + kernel_ms slot
-        self.frame = torch.zeros((self.H, self.W, 3), dtype=torch.float32, device=self.dev) if rank == 0 else None
-        self.gathered = (torch.zeros((world, self.tpr, tile, tile, 3), dtype=torch.float32, device=self.dev)
-                         if (rank == 0 and world > 1) else None)
+        self.F = frames_in_flight
+        self.slots = [_Slot(self, torch.cuda.Stream(self.dev) if self.F > 1 else None) for _ in range(self.F)]
+        for sl in self.slots:
+            if sl.stream is not None:
+                self.dscene.bind_stream(sl.stream.cuda_stream)
+        self._submitted = 0
+        s0 = self.slots[0]                                      # the single-frame interface works on slot 0
+        self.shard, self.stats, self.frame, self.gathered = s0.shard, s0.stats, s0.frame, s0.gathered
 
-    def render_shard(self):
+    def render_shard(self, slot=0):
         """Enqueue this rank's tiles on torch's current stream (no host sync)."""
+        sl = self.slots[slot]
         stream = torch.cuda.current_stream(self.dev).cuda_stream
-        self.dscene.render_tiles_async(self.shard.data_ptr(), self.tile, self.rank, self.world,
-                                       stats_dev_ptr=self.stats.data_ptr(), stream=stream)
+        self.dscene.render_tiles_async(sl.shard.data_ptr(), self.tile, self.rank, self.world,
+                                       stats_dev_ptr=sl.stats.data_ptr(), stream=stream)
 
-    def gather(self):
+    def gather(self, slot=0):
         """The one exchange step: compacted shards -> rank 0 (direct peer->root, not a ring), then de-interleave."""
+        sl = self.slots[slot]
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         if self.world > 1:
             import torch.distributed as dist
             if self.rank == 0:
-                dist.gather(self.shard, list(self.gathered.unbind(0)), dst=0)
-                src = self.gathered
+                dist.gather(sl.shard, list(sl.gathered.unbind(0)), dst=0)
+                src = sl.gathered
             else:
-                dist.gather(self.shard, None, dst=0)
+                dist.gather(sl.shard, None, dst=0)
                 return None
         else:
-            src = self.shard
-        device.untile_async(src.data_ptr(), self.frame.data_ptr(), self.W, self.H, self.tile, self.world, self.tpr,
+            src = sl.shard
+        device.untile_async(src.data_ptr(), sl.frame.data_ptr(), self.W, self.H, self.tile, self.world, self.tpr,
                             stream=stream)
-        return self.frame
+        return sl.frame
+
+    def submit_frame(self):
+        """Enqueue one whole frame (trace + gather + de-interleave) on the next slot's stream and return the slot index;
+        no host sync.  Every rank must submit frames in the same order (the gathers are collectives).  The frame of
+        slot k is complete after wait(k); it is overwritten by the F-th submit after this one."""
+        k = self._submitted % self.F
+        self._submitted += 1
+        sl = self.slots[k]
+        if sl.stream is None:
+            self.render_shard(k)
+            self.gather(k)
+        else:
+            sl.stream.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(sl.stream):
+                self.render_shard(k)
+                self.gather(k)
+        return k
+
+    def wait(self, slot=None):
+        """Host-wait for one slot's stream (or all of them) and return that slot's frame (rank 0) or None."""
+        for k, sl in enumerate(self.slots):
+            if slot is None or k == slot:
+                (sl.stream or torch.cuda.current_stream(self.dev)).synchronize()
+        return self.slots[slot or 0].frame
 
     def render_frame(self, antialias=None):
         """RenderScene: every rank traces its tiles, rank 0 gathers; if settings.wantAA (or antialias=True) rank 0 then

@@ -278,3 +278,44 @@ def test_frame_renderer_runs_the_aa_pass_on_the_gathered_frame(load_scene):
     assert np.abs(frame - ref).max() <= SUM_ORDER_TOL
     first, _, _ = device.DeviceScene(s).render()
     assert np.abs(frame - first).max() > 1e-3        # the pass changed something
+
+
+def test_frames_in_flight_give_the_single_frame(load_scene):
+    """Frames on different HIP streams use separate working sets of the scene (qd_scene_bind_stream) and overlap on the
+    GPU; every one of them must be the frame a lone render gives.  Six streams on one scene also exercise the take-over
+    of the working set used longest ago (the library keeps four)."""
+    import torch
+    from raytracing_amd import renderer
+    s = load_scene("kdtree_teapot_lowres_env.qdmg")
+    old = _aa_settings(s, want_aa=0)
+    try:
+        W, H = s.settings.frame_width, s.settings.frame_height
+        fr = renderer.FrameRenderer(s, tile=32, rank=0, world=1, local_device=0, frames_in_flight=3)
+        try:
+            ref, _, ref_stats = fr.dscene.render()
+            frames = []
+            for i in range(7):
+                k = fr.submit_frame()
+                if i >= 4:                                  # the last three submits: one per slot, still in flight together
+                    frames.append(k)
+            got = [fr.wait(k).cpu().numpy() for k in frames]
+            fr.check()
+            assert sorted(frames) == [0, 1, 2]
+            for g in got:
+                assert np.abs(g - ref).max() <= SUM_ORDER_TOL
+            assert fr.stats_dict()["rays"] == ref_stats["rays"]
+            # six streams, one shard buffer each, enqueued back to back
+            tile, tpr = 32, sharding.tiles_per_rank_padded(W, H, 32, 1)
+            streams = [torch.cuda.Stream() for _ in range(6)]
+            shards = [torch.zeros((tpr, tile, tile, 3), dtype=torch.float32, device="cuda:0") for _ in streams]
+            for st_, sh in zip(streams, shards):
+                fr.dscene.render_tiles_async(sh.data_ptr(), tile, 0, 1, stream=st_.cuda_stream)
+            torch.cuda.synchronize()
+            fr.check()
+            for sh in shards:
+                img = sharding.untile(sh.cpu().numpy()[None], W, H, tile, 1)
+                assert np.abs(img - ref).max() <= SUM_ORDER_TOL
+        finally:
+            fr.dscene.close()
+    finally:
+        _aa_settings(s, **old)
