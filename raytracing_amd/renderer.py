@@ -55,18 +55,21 @@ class FrameRenderer:
         self.dscene.render_tiles_async(sl.shard.data_ptr(), self.tile, self.rank, self.world,
                                        stats_dev_ptr=sl.stats.data_ptr(), stream=stream)
 
+    def _gather_shards(self, sl):
+        """Compacted shards of every rank -> sl.gathered on rank 0 (equal sizes; RCCL sends each peer's shard straight
+        to the root over that peer's own xGMI link, not around a ring)."""
+        import torch.distributed as dist
+        dist.gather(sl.shard, list(sl.gathered.unbind(0)) if self.rank == 0 else None, dst=0)
+
     def gather(self, slot=0):
-        """The one exchange step: compacted shards -> rank 0 (direct peer->root, not a ring), then de-interleave."""
+        """The one exchange step: compacted shards -> rank 0, then de-interleave."""
         sl = self.slots[slot]
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         if self.world > 1:
-            import torch.distributed as dist
-            if self.rank == 0:
-                dist.gather(sl.shard, list(sl.gathered.unbind(0)), dst=0)
-                src = sl.gathered
-            else:
-                dist.gather(sl.shard, None, dst=0)
+            self._gather_shards(sl)
+            if self.rank != 0:
                 return None
+            src = sl.gathered
         else:
             src = sl.shard
         device.untile_async(src.data_ptr(), sl.frame.data_ptr(), self.W, self.H, self.tile, self.world, self.tpr,

@@ -1,0 +1,88 @@
+"""The multi-rank frame path with the real kernels on a one-GPU box: two ranks, both on cuda:0, run FrameRenderer with
+frames in flight -- trace on per-slot HIP streams, gather to rank 0, de-interleave -- and every frame must be the
+frame a lone qd_render gives.  RCCL refuses two ranks on one GPU, and gloo's device-tensor gather hangs on this
+ROCm build whenever a kernel is still in flight on the stream (a plain matmul is enough), so the test swaps the
+collective only: shard -> host, gloo gather of host tensors, -> device.  Slots, streams, working sets, submit order and
+the de-interleave of a two-rank frame are the product's.  bench.py drives the same calls, one rank per GPU, over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SUM_ORDER_TOL = 2e-6       # two device renders of the same pixel: float additions in a different order
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, flight, out_path):
+    import datetime
+    sys.path.insert(0, ROOT)
+    log = open(f"{out_path}.rank{rank}.log", "w")
+
+    def note(msg):
+        log.write(msg + "\n"); log.flush()
+
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import host, renderer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+    note("init")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    note("group up")
+    s = host.Scene.load(os.path.join(ROOT, "tests", "golden", "data", "kdtree_teapot_lowres_env.qdmg"))
+    s.settings.want_aa = 0
+    class HostGather(renderer.FrameRenderer):
+        def _gather_shards(self, sl):
+            cur = torch.cuda.current_stream(self.dev)
+            cur.synchronize()
+            mine = sl.shard.cpu()
+            got = [torch.zeros_like(mine) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(mine, got, dst=0)
+            if self.rank == 0:
+                sl.gathered.copy_(torch.stack(got))
+
+    fr = HostGather(s, tile=32, rank=rank, world=world, local_device=0, frames_in_flight=flight)
+    note("scene on device")
+    slots = [fr.submit_frame() for _ in range(2 * flight + 1)][-flight:]
+    note("submitted")
+    frames = [fr.wait(k) for k in slots]
+    fr.check()
+    note("frames complete")
+    if rank == 0:
+        ref, _, _ = fr.dscene.render()
+        worst = max(float(np.abs(f.cpu().numpy() - ref).max()) for f in frames)
+        np.save(out_path, np.array([worst, float(sorted(slots) == list(range(flight)))]))
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+    fr.dscene.close()
+
+
+@pytest.mark.parametrize("flight", [1, 3])
+def test_two_ranks_with_frames_in_flight(tmp_path, flight):
+    out = str(tmp_path / "res.npy")
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, flight, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=100)
+    logs = " | ".join(open(f"{out}.rank{r}.log").read().replace("\n", ",") if os.path.exists(f"{out}.rank{r}.log") else "-" for r in range(2))
+    stuck = [p for p in procs if p.is_alive()]
+    for p in stuck:
+        p.kill()
+        p.join()
+    assert not stuck, f"ranks did not finish; progress: {logs}"
+    assert all(p.exitcode == 0 for p in procs), f"exit codes {[p.exitcode for p in procs]}; progress: {logs}"
+    worst, slots_ok = np.load(out)
+    assert slots_ok == 1.0
+    assert worst <= SUM_ORDER_TOL, worst
