@@ -69,7 +69,11 @@ def build_device(force=False):
     if force or _newer(out, srcs + _headers(src_dir, INC)):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-              "-ffp-contract=off", "-fno-fast-math", "-I", INC, "-I", src_dir, *srcs, "-o", out])
+              "-ffp-contract=off", "-fno-fast-math",
+              # machine LICM hoists the polynomial constants of rarely taken paths (asin/atan2 of the sphere's uv, the
+              # bump sines) to the top of trace_nodes and spills them there on every call: 164 -> 45 spilled VGPRs, +13 %
+              "-mllvm", "-disable-machine-licm",
+              "-I", INC, "-I", src_dir, *srcs, "-o", out])
     return out
 
 
