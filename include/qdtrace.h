@@ -296,6 +296,14 @@ int qd_untile_async(const float* src_dev, float* dst_dev, int width, int height,
 int qd_quantize_bgr8_async(const float* rgb_dev, uint8_t* bgr_dev, int width, int height,
                            size_t row_bytes, void* hip_stream);
 
+/* Replaces: Color::toRGB32 / Color::toSRGB32 (src/color.cpp:16-36) as DisplayVFB / DisplayVFBRect apply them
+ * to every pixel of the frame or of a finished bucket (src/sdl.cpp:38-52, 302-322; useSRGB from GlobalSettings,
+ * src/main.cpp:99): float rgb image (device, row pitch in floats) -> one packed 32-bit word per pixel,
+ * (b << blue_shift) | (g << green_shift) | (r << red_shift), channels through ConvertTo8Bit or, with use_srgb,
+ * ConvertTo8Bit_sRGB (src/utils.h:34-35).  The reference's defaults are shifts 16 / 8 / 0. */
+int qd_pack_rgb32_async(const float* rgb_dev, size_t row_pitch_floats, uint32_t* out_dev, int width, int height,
+                        int use_srgb, int red_shift, int green_shift, int blue_shift, void* hip_stream);
+
 /* Counting build of the kernels: when on, renders also fill kd_nodes_visited / tris_tested /
  * mesh_queries (the reference's debug counters nbBBoxIntersections / nbTriIntersections /
  * nbIntersections, src/mesh.cpp:20-22); off by default because the counters cost registers. */

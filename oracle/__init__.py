@@ -43,6 +43,8 @@ def lib():
         L.orc_render_frame.argtypes = [P(abi.QdSceneDesc), C.c_void_p, C.c_int, P(OrcStats)]
         L.orc_convert_to_8bit.restype = C.c_uint
         L.orc_convert_to_8bit.argtypes = [C.c_double]
+        L.orc_to_rgb32.restype = None
+        L.orc_to_rgb32.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -91,3 +93,11 @@ def render_frame(scene, rng_mode=0):
     if lib().orc_render_frame(scene.desc_ptr, rgb.ctypes.data, rng_mode, C.byref(st)) != 0:
         raise RuntimeError("orc_render_frame failed")
     return rgb, st.as_dict()
+
+
+def to_rgb32(rgb, srgb=False, shifts=(16, 8, 0)):
+    """Color::toRGB32 / toSRGB32 (src/color.cpp:16-36) for every pixel of float32[..., 3] -> uint32[...]."""
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    out = np.zeros(rgb.shape[:-1], np.uint32)
+    lib().orc_to_rgb32(rgb.ctypes.data, out.size, 1 if srgb else 0, shifts[0], shifts[1], shifts[2], out.ctypes.data)
+    return out

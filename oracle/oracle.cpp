@@ -973,3 +973,15 @@ extern "C" unsigned orc_convert_to_8bit(double x) {   // ConvertTo8Bit, src/util
     const double cl = std::min(std::max(x, (double)0.f), (double)1.f);
     return (unsigned)(int)std::floor(cl * 255.f + 0.5);
 }
+
+// Color::toRGB32 / toSRGB32 (src/color.cpp:16-36) with ConvertTo8Bit / ConvertTo8Bit_sRGB (src/utils.h:34-35)
+extern "C" void orc_to_rgb32(const float* rgb, size_t n_pixels, int srgb, int rs, int gs, int bs, unsigned* out) {
+    for (size_t i = 0; i < n_pixels; ++i) {
+        unsigned c[3];
+        for (int k = 0; k < 3; ++k) {
+            const double x = rgb[i * 3 + k];
+            c[k] = orc_convert_to_8bit(srgb ? (x <= 0.0031308 ? x * 12.92 : 1.055 * std::pow(x, 1 / 2.4) - 0.055) : x);
+        }
+        out[i] = (c[2] << bs) | (c[1] << gs) | (c[0] << rs);
+    }
+}

@@ -681,6 +681,21 @@ __global__ void quantize_kernel(const float* __restrict__ rgb, uint8_t* __restri
     o[0] = q8(p[2]); o[1] = q8(p[1]); o[2] = q8(p[0]);
 }
 
+// Color::toRGB32 / toSRGB32 (src/color.cpp:16-36) as DisplayVFBRect applies them per pixel (src/sdl.cpp:302-322):
+// ConvertTo8Bit or ConvertTo8Bit_sRGB (src/utils.h:34-35) per channel, packed with the surface's channel shifts.
+__global__ void pack_rgb32_kernel(const float* __restrict__ rgb, size_t pitch, uint32_t* __restrict__ out, int W, int H, int srgb,
+                                  int rs, int gs, int bs) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    const float* p = rgb + (size_t)y * pitch + (size_t)x * 3;
+    auto q8 = [srgb](float v) {
+        double c = (double)v;
+        if (srgb) c = c <= 0.0031308 ? c * 12.92 : 1.055 * pow(c, 1 / 2.4) - 0.055;
+        c = fmin(fmax(c, 0.0), 1.0);
+        return (uint32_t)(int)floor(c * 255.0 + 0.5);
+    };
+    out[(size_t)y * W + x] = (q8(p[2]) << bs) | (q8(p[1]) << gs) | (q8(p[0]) << rs);
+}
 
 // ------------------------------------------------------------------------------------------ anti-aliasing pass
 // RenderScene's second pass (src/main.cpp:106-153) and IsTooDifferent (:58-83).  The reference walks the
@@ -1334,6 +1349,16 @@ extern "C" int qd_untile_async(const float* src_dev, float* dst_dev, int width, 
 extern "C" int qd_quantize_bgr8_async(const float* rgb_dev, uint8_t* bgr_dev, int width, int height, size_t row_bytes, void* hip_stream) {
     if (!rgb_dev || !bgr_dev || width <= 0 || height <= 0 || row_bytes < (size_t)width * 3) return set_err("qd_quantize_bgr8_async: bad argument");
     hipLaunchKernelGGL(quantize_kernel, dim3((width + 255) / 256, height), dim3(256), 0, (hipStream_t)hip_stream, rgb_dev, bgr_dev, width, height, row_bytes);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int qd_pack_rgb32_async(const float* rgb_dev, size_t row_pitch_floats, uint32_t* out_dev, int width, int height, int use_srgb,
+                                   int red_shift, int green_shift, int blue_shift, void* hip_stream) {
+    if (!rgb_dev || !out_dev || width <= 0 || height <= 0 || row_pitch_floats < (size_t)width * 3) return set_err("qd_pack_rgb32_async: bad argument");
+    for (int sh : {red_shift, green_shift, blue_shift}) if (sh < 0 || sh > 24) return set_err("qd_pack_rgb32_async: channel shift outside 0..24");
+    hipLaunchKernelGGL(pack_rgb32_kernel, dim3((width + 255) / 256, height), dim3(256), 0, (hipStream_t)hip_stream, rgb_dev, row_pitch_floats, out_dev,
+                       width, height, use_srgb, red_shift, green_shift, blue_shift);
     HIP_TRY(hipGetLastError());
     return 0;
 }

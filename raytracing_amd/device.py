@@ -38,6 +38,7 @@ def lib():
         L.qd_scene_bind_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.qd_untile_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.qd_quantize_bgr8_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
+        L.qd_pack_rgb32_async.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.qd_set_kd_refine.argtypes = [C.c_int, C.c_double]
         L.qd_scene_kd_info.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
         for name in abi.QDTRACE_SYMBOLS:
@@ -122,6 +123,22 @@ class DeviceScene:
                 stats[k] += aa[k]
         return rgb, stats
 
+    def render_buckets(self, on_bucket=None, camera=None, settings=None):
+        """SimpleRender (src/main.cpp:85-104): the frame bucket by bucket in GetBucketList order (src/sdl.cpp:253-276);
+        after each bucket `on_bucket((x0, y0, x1, y1), frame)` plays DisplayVFBRect -- returning False stops the render
+        there, as the reference does when the user closes the window (src/main.cpp:99-100), and the call returns
+        (frame, False) with the buckets finished so far."""
+        from . import host
+        st = settings if settings is not None else self.host_scene.settings
+        W, H = st.frame_width, st.frame_height
+        frame = np.zeros((H, W, 3), np.float32)
+        for (x0, y0, x1, y1) in host.bucket_list(W, H):
+            rgb, _, _ = self.render(int(x0), int(y0), int(x1), int(y1), camera=camera, settings=settings)
+            frame[y0:y1, x0:x1] = rgb
+            if on_bucket is not None and on_bucket((int(x0), int(y0), int(x1), int(y1)), frame) is False:
+                return frame, False
+        return frame, True
+
     def render_tiles_async(self, rgb_dev_ptr, tile, phase, stride, stats_dev_ptr=None, stream=None,
                            camera=None, settings=None):
         st = settings if settings is not None else self.host_scene.settings
@@ -168,3 +185,9 @@ def quantize_bgr8_async(rgb_ptr, out_ptr, width, height, row_bytes, stream=None)
 def tiles_owned(width, height, tile, phase, stride):
     n_tiles = ((width + tile - 1) // tile) * ((height + tile - 1) // tile)
     return (n_tiles - phase + stride - 1) // stride if n_tiles > phase else 0
+
+
+def pack_rgb32_async(rgb_ptr, pitch_floats, out_ptr, width, height, use_srgb=False, shifts=(16, 8, 0), stream=None):
+    """Color::toRGB32 / toSRGB32 per pixel of a device image (what DisplayVFBRect shows)."""
+    _check(lib().qd_pack_rgb32_async(C.c_void_p(rgb_ptr), pitch_floats, C.c_void_p(out_ptr), width, height, 1 if use_srgb else 0,
+                                     shifts[0], shifts[1], shifts[2], C.c_void_p(stream or 0)), "qd_pack_rgb32_async")

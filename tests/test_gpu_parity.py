@@ -157,6 +157,44 @@ def test_quantize_kernel_matches_convert_to_8bit():
     assert oracle.lib().orc_convert_to_8bit(0.5) == got[36, 0, 2]
 
 
+def test_pack_rgb32_kernel_matches_to_rgb32():
+    """qd_pack_rgb32_async == Color::toRGB32 / toSRGB32 per pixel (what DisplayVFBRect shows), bit for bit."""
+    import torch
+    rng = np.random.default_rng(5)
+    img = (rng.random((41, 67, 3), dtype=np.float32) * 1.3 - 0.15)
+    img[0, :8, 0] = [0.0, 0.0031308, 0.0031309, 0.5, 1.0, 0.2, -1.0, 4.0]
+    t = torch.from_numpy(img).cuda()
+    out = torch.zeros((41, 67), dtype=torch.int32, device="cuda:0")
+    for srgb in (False, True):
+        for shifts in ((16, 8, 0), (0, 8, 16)):
+            device.pack_rgb32_async(t.data_ptr(), 67 * 3, out.data_ptr(), 67, 41, use_srgb=srgb, shifts=shifts)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy().view(np.uint32), oracle.to_rgb32(img, srgb=srgb, shifts=shifts)), (srgb, shifts)
+
+
+def test_bucket_by_bucket_render_and_cancel(load_scene):
+    """SimpleRender's loop (src/main.cpp:85-104): buckets in GetBucketList order, a display hook per bucket whose False
+    stops the render; the finished frame equals the single-rectangle frame."""
+    s = load_scene("kdtree_teapot_lowres_env.qdmg")
+    old = _aa_settings(s, want_aa=0)
+    ds = device.DeviceScene(s)
+    try:
+        full, _, _ = ds.render()
+        seen = []
+        frame, done = ds.render_buckets(lambda r, f: seen.append(r))
+        assert done and seen == [tuple(int(v) for v in b) for b in host.bucket_list(s.settings.frame_width, s.settings.frame_height)]
+        assert np.abs(frame - full).max() <= SUM_ORDER_TOL
+        part, done = ds.render_buckets(lambda r, f: len(seen) < 0 or r != seen[2])
+        assert not done
+        x0, y0, x1, y1 = seen[2]
+        assert np.abs(part[y0:y1, x0:x1] - full[y0:y1, x0:x1]).max() <= SUM_ORDER_TOL
+        x0, y0, x1, y1 = seen[3]
+        assert not part[y0:y1, x0:x1].any()                     # never started
+    finally:
+        ds.close()
+        _aa_settings(s, **old)
+
+
 def test_nested_layered_and_csg_are_rejected_loudly(tmp_path):
     p = tmp_path / "n.qdmg"
     p.write_text("Camera c {\n position (0,0,-5)\n}\nSphere s {\n}\nConst k {\n}\nLayered a {\n layer k (1,1,1)\n}\n"

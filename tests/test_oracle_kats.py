@@ -90,3 +90,12 @@ def test_kd_walk_equals_brute_force(load_scene, tmp_path, data_dir):
 
 def test_quantisation():
     assert [oracle.lib().orc_convert_to_8bit(v) for v in (-1.0, 0.0, 0.5, 0.999, 1.0, 7.0)] == [0, 0, 128, 255, 255, 255]
+
+
+def test_to_rgb32_known_values():
+    """Color::toRGB32 / toSRGB32 (src/color.cpp:16-36): shifts 16/8/0, ConvertTo8Bit / ConvertTo8Bit_sRGB per channel.
+    Known answers: sRGB of 0.5 is 188 (0.7354 * 255 = 187.5 -> 188), of 0.0031308 is 10 (0.04045 * 255 = 10.3), of 0.2 is 124."""
+    px = np.array([[0.5, 1.0, 0.0], [0.2, 0.0031308, -3.0], [2.0, 0.999, 0.5]], np.float32)
+    assert oracle.to_rgb32(px).tolist() == [(128 << 16) | (255 << 8), (51 << 16) | (1 << 8), (255 << 16) | (255 << 8) | 128]
+    assert oracle.to_rgb32(px, srgb=True).tolist() == [(188 << 16) | (255 << 8), (124 << 16) | (10 << 8), (255 << 16) | (255 << 8) | 188]
+    assert oracle.to_rgb32(px[:1], shifts=(0, 8, 16)).tolist() == [128 | (255 << 8)]
