@@ -21,3 +21,8 @@ noenv() { awk '/^CubemapEnvironment/{skip=1} {if(!skip)print} /^}/{skip=0}'; }
 fix $R/kdtree_test.qdmg | sed -e 's#geometries/Gas-and-oil-pumps_high.obj#geometries/teapot_lowres.obj#' | noenv > $D/kdtree_teapot_lowres_noenv.qdmg
 fix $R/kdtree_test.qdmg | sed -e 's#geometries/Gas-and-oil-pumps_high.obj#geometries/1-low.obj#' | noenv > $D/kdtree_1low_noenv.qdmg
 fix $R/kdtree_test.qdmg | sed -e 's#geometries/Gas-and-oil-pumps_high.obj#geometries/teapot_hires.obj#' -e 's/^\(\s*useKDTree true\)/\1\n\tuseSAH true/' | noenv > $D/kdtree_teapot_hires_sah_noenv.qdmg
+# the two remaining shipped scenes parse as they are: copied with their meshes (wantAA off like the others)
+mkdir -p $D/hw9
+fix $R/hw9/axe_test.qdmg > $D/hw9/axe_test.qdmg
+fix $R/hw9/testmesh.qdmg > $D/hw9/testmesh.qdmg
+cp $R/hw9/axe_lo.obj $D/hw9/; cp $R/geometries/heart.obj $R/geometries/newwine.obj $D/geometries/

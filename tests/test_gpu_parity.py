@@ -18,7 +18,7 @@ COLOUR_TOL = 1e-4
 NEAR_TIE_BUDGET = 1e-4     # 0.01 % of pixels
 SUM_ORDER_TOL = 2e-6       # two device renders of the same pixel: float additions in a different order
 
-SCENES = ["hw9/nonconvex.qdmg", "window_fixed.qdmg", "bumpmap_fixed.qdmg", "lecture7_fixed.qdmg",
+SCENES = ["hw9/nonconvex.qdmg", "hw9/axe_test.qdmg", "hw9/testmesh.qdmg", "hw9/dragon.qdmg", "window_fixed.qdmg", "bumpmap_fixed.qdmg", "lecture7_fixed.qdmg",
           "heightfield_fixed.qdmg", "kdtree_teapot_lowres_env.qdmg", "kdtree_teapot_hires_sah_noenv.qdmg",
           "kdtree_fixed.qdmg"]
 
