@@ -21,6 +21,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# One hardware queue per frame in flight (plus RCCL's): HIP gives a process 4 by default and streams beyond that share
+# a queue and serialise.  Read by the HIP runtime when it is loaded, i.e. before `import torch` below.
+if int(os.environ.get("GPU_MAX_HW_QUEUES") or 0) < 8:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -84,7 +88,7 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames enqueued at a time, one HIP stream each (1 = strictly one after the other; 0 = by shard size: 2 at 1 GPU, 3 at 2, 4 beyond)")
+                    help="frames enqueued at a time, one HIP stream each (1 = strictly one after the other; 0 = by shard size: 2 at 1 GPU, 3 at 2, 4 at 4, 6 beyond)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kd-refine", default=None, help="'max_leaf,step_cost' for qd_set_kd_refine (tuning; default = library default)")
     args = ap.parse_args()
@@ -110,7 +114,7 @@ def main():
 
     if args.frames_in_flight == 0:
         # frames needed to keep the chip full ~ critical path of a frame (4-5 ms of dependent ray generations) / work per shard
-        args.frames_in_flight = 2 if world == 1 else 3 if world == 2 else 4
+        args.frames_in_flight = 2 if world == 1 else 3 if world == 2 else 4 if world <= 4 else 6
     if args.kd_refine:
         ml, sc = args.kd_refine.split(",")
         device.set_kd_refine(int(ml), float(sc))

@@ -270,10 +270,10 @@ int qd_antialias_device(qd_scene* scene, const qd_camera* camera, const qd_setti
  * one process per GPU) and writes them *compacted*: owned tile number k (in
  * increasing t) occupies rgb_dev[k*tile*tile*3 ...], row-major inside the tile.
  * Used by bench.py / the RCCL gather path.  stats_dev: optional device qd_stats.
- * Frames in flight: a scene keeps up to 4 working sets (ray queues, task lists, control words),
+ * Frames in flight: a scene keeps up to 8 working sets (ray queues, task lists, control words),
  * each bound to the stream that used it last.  Calls on ONE stream share a set and run in order;
  * calls on DIFFERENT streams use different sets and may overlap on the GPU (the thin tail of one
- * frame runs beside the start of the next) -- give each such call its own rgb_dev / stats_dev.  A fifth
+ * frame runs beside the start of the next) -- give each such call its own rgb_dev / stats_dev.  A ninth
  * stream takes over the set used longest ago and first waits, on the device, for that set's last launch. */
 int qd_render_tiles_async(qd_scene* scene, const qd_camera* camera, const qd_settings* settings,
                           int tile, int tile_phase, int tile_stride,

@@ -803,7 +803,7 @@ int set_err(const std::string& m) { g_err = m; return -1; }
 // control words.  A scene holds up to kMaxWorkSets of them, each bound to the HIP stream that used it last, so frames
 // rendered on different streams overlap on the GPU: the tail of one frame (few waves walking the last generations of
 // their ray trees) runs beside the start of the next.  Launches on one stream share a set and serialise as before.
-constexpr int kMaxWorkSets = 4;              // = hardware queues a process gets on this pool (GPU_MAX_HW_QUEUES)
+constexpr int kMaxWorkSets = 8;              // streams beyond the process's hardware queues (GPU_MAX_HW_QUEUES, 4 by default) share one and serialise
 struct WorkSet {
     bool bound = false;
     hipStream_t stream = nullptr;

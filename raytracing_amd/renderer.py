@@ -29,8 +29,8 @@ class FrameRenderer:
     last ray generations keep only a few waves busy and the next frame's pixels fill the rest of the chip."""
 
     def __init__(self, scene, tile=32, rank=0, world=1, local_device=0, frames_in_flight=1):
-        if not 1 <= frames_in_flight <= 4:
-            raise ValueError("frames_in_flight must be 1..4 (working sets per scene in libqdtrace)")
+        if not 1 <= frames_in_flight <= 8:
+            raise ValueError("frames_in_flight must be 1..8 (working sets per scene in libqdtrace)")
         self.scene, self.tile, self.rank, self.world = scene, tile, rank, world
         self.dev = torch.device("cuda", local_device)
         torch.cuda.set_device(self.dev)

@@ -4,6 +4,8 @@ usage: flight_probe.py [n] [worlds] [Fmax]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if int(os.environ.get("GPU_MAX_HW_QUEUES") or 0) < 8:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"   # as bench.py does, before the HIP runtime is loaded
 import torch
 from raytracing_amd import host, renderer
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2240

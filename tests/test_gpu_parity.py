@@ -320,8 +320,8 @@ def test_frame_renderer_runs_the_aa_pass_on_the_gathered_frame(load_scene):
 
 def test_frames_in_flight_give_the_single_frame(load_scene):
     """Frames on different HIP streams use separate working sets of the scene (qd_scene_bind_stream) and overlap on the
-    GPU; every one of them must be the frame a lone render gives.  Six streams on one scene also exercise the take-over
-    of the working set used longest ago (the library keeps four)."""
+    GPU; every one of them must be the frame a lone render gives.  Ten streams on one scene also exercise the take-over
+    of the working set used longest ago (the library keeps eight)."""
     import torch
     from raytracing_amd import renderer
     s = load_scene("kdtree_teapot_lowres_env.qdmg")
@@ -342,9 +342,9 @@ def test_frames_in_flight_give_the_single_frame(load_scene):
             for g in got:
                 assert np.abs(g - ref).max() <= SUM_ORDER_TOL
             assert fr.stats_dict()["rays"] == ref_stats["rays"]
-            # six streams, one shard buffer each, enqueued back to back
+            # ten streams, one shard buffer each, enqueued back to back
             tile, tpr = 32, sharding.tiles_per_rank_padded(W, H, 32, 1)
-            streams = [torch.cuda.Stream() for _ in range(6)]
+            streams = [torch.cuda.Stream() for _ in range(10)]
             shards = [torch.zeros((tpr, tile, tile, 3), dtype=torch.float32, device="cuda:0") for _ in streams]
             for st_, sh in zip(streams, shards):
                 fr.dscene.render_tiles_async(sh.data_ptr(), tile, 0, 1, stream=st_.cuda_stream)
