@@ -169,8 +169,12 @@ def main():
     device.set_counting(False)
     owned_px = sum((x1 - x0) * (y1 - y0) for (x0, y0, x1, y1) in
                    __import__("raytracing_amd.sharding", fromlist=["x"]).owned_tile_rects(W, H, args.tile, rank, world))
-    # 16 B per KD node visited + 76 B per triangle tested (72 B vertices + 4 B index) + 12 B per pixel written
-    alg_bytes = 16.0 * cstats["kd_nodes_visited"] + 76.0 * cstats["tris_tested"] + 12.0 * owned_px
+    # 16 B per KD node visited + 76 B per triangle tested (72 B vertices + 4 B index) + 12 B per pixel written;
+    # a scene whose traversal is a heightfield DDA instead: 68 B per DDA step (4 B maxHeight + one 64 B highmap line) + 16 B
+    # per cell tested (four heights).  The counting build tallies steps with the node visits and cells with the triangle tests.
+    hf_scene = scene.desc.n_hfields > 0 and scene.desc.n_tris == 0
+    per_visit, per_test = (68.0, 16.0) if hf_scene else (16.0, 76.0)
+    alg_bytes = per_visit * cstats["kd_nodes_visited"] + per_test * cstats["tris_tested"] + 12.0 * owned_px
 
     if rank == 0:
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -194,7 +198,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "trace_kernel", "kernel_ms": kernel_ms, "launches_per_step": 3,
                          "note": "one frame = 3 launches of trace_kernel (pixels, then two passes over handed-over ray tasks, usually empty); kernel_ms, achieved and traffic are per frame = the sum over the three, measured on launches that run alone (a separate untimed loop after the timed region; rocprofv3 of `bench.py --frames-in-flight 1`: TotalDurationNs / frames); the timed region overlaps frames, so ms_per_step can be below kernel_ms",
-                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_visit_and_test": [per_visit, per_test],
                          "kd_nodes_visited": cstats["kd_nodes_visited"], "tris_tested": cstats["tris_tested"]},
         }
         if world == 1 and not args.no_cpu_baseline:

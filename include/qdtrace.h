@@ -214,8 +214,9 @@ typedef struct qd_stats {
     uint64_t primary_rays;
     uint64_t shadow_rays;
     uint64_t depth_killed;    /* Raytrace calls cut by ray.depth > maxTraceDepth       */
-    uint64_t kd_nodes_visited;/* KD nodes touched (inner + leaf)                        */
-    uint64_t tris_tested;     /* triangle tests after back-face culling (nbTriIntersections, src/mesh.cpp:116) */
+    uint64_t kd_nodes_visited;/* KD nodes touched (inner + leaf); plus, for heightfields, DDA steps (src/heightfield.cpp:33) */
+    uint64_t tris_tested;     /* triangle tests after back-face culling (nbTriIntersections, src/mesh.cpp:116);
+                               * plus, for heightfields, cells whose two triangles were tested (src/heightfield.cpp:50-58) */
     uint64_t mesh_queries;    /* ray/mesh queries that pass the mesh bbox (nbIntersections, src/mesh.cpp:38)     */
     double   kernel_ms;       /* device time of the trace kernel(s), HIP events         */
 } qd_stats;

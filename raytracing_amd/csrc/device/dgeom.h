@@ -386,7 +386,10 @@ QD_DEV bool tri_fast(const DV& start, const DV& dir, const DV& A, const DV& B, c
 }
 
 // ---------------------------------------------------------------- heightfield (src/heightfield.cpp:20-100, :216-245)
-QD_DEV bool hf_intersect(const DScene& S, int hf, const DV& start, const DV& dir, double& out_dist) {
+// Counting build: n_steps = DDA steps (one maxHeight word + one 64-byte highmap line each), n_cells = cells whose two
+// triangles were tested (four heights = 16 B) -- SURVEY.md 8(d)'s units for the heightfield workload.
+template <bool STATS>
+QD_DEV bool hf_intersect(const DScene& S, int hf, const DV& start, const DV& dir, double& out_dist, uint32_t& n_steps, uint32_t& n_cells) {
     const qd_heightfield& h = S.hfields[hf];
     const float* heights = S.hf_f32 + h.heights_off;
     const float* maxh = S.hf_f32 + h.maxheights_off;
@@ -398,6 +401,7 @@ QD_DEV bool hf_intersect(const DScene& S, int hf, const DV& start, const DV& dir
     const double mx = 1.0 / dir.x, mz = 1.0 / dir.z;
     DV p = start + dir * (dist + 1e-6);
     while (box_inside(h.bbox_min, h.bbox_max, p)) {
+        if (STATS) ++n_steps;
         int x0 = (int)floor(p.x), z0 = (int)floor(p.z);
         if (!(x0 < 0 || x0 >= W || z0 < 0 || z0 >= H) && h.use_optimization) {
             int k = 0;
@@ -414,6 +418,7 @@ QD_DEV bool hf_intersect(const DScene& S, int hf, const DV& start, const DV& dir
         const DV p_next = p + step * (fmin(lx, lz) + 1e-6);
         if (fmin(p.y, p_next.y) < (double)maxh[(size_t)z0 * W + x0]) {
             double closest = kInf;
+            if (STATS) ++n_cells;
             const DV A = mk(x0, get_height(x0, z0), z0);
             const DV B = mk(x0 + 1, get_height(x0 + 1, z0), z0);
             const DV C = mk(x0 + 1, get_height(x0 + 1, z0 + 1), z0 + 1);

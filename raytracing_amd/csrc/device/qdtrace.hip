@@ -175,7 +175,7 @@ __device__ QD_OUTLINE int trace_nodes(const DScene& S, const DV& o, const DV& d,
             cnt.t_b += QD_STAMP() - ta1;
         } else if (g.type == QD_GEOM_HEIGHTFIELD) {
             if (final_pass) { hf_finish(S, g.a, r.o, r.d, w_dist, hit); break; }
-            got = hf_intersect(S, g.a, r.o, r.d, dist);
+            got = hf_intersect<STATS>(S, g.a, r.o, r.d, dist, cnt.kd_nodes, cnt.tris);
         } else {
             GHit h;
             got = analytic_intersect(S, g, r.o, r.d, h);

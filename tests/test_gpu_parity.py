@@ -141,6 +141,27 @@ def test_4k_heightfield_properties(load_scene):
         st.frame_width, st.frame_height, st.want_aa = old
 
 
+def test_counting_build_tallies_heightfield_steps(load_scene):
+    """bench.py prices the heightfield workload on DDA steps and cells tested; the counting build reports
+    them in kd_nodes_visited / tris_tested, and counting changes nothing else."""
+    s = load_scene("heightfield_fixed.qdmg")
+    old = _aa_settings(s, want_aa=0)
+    ds = device.DeviceScene(s)
+    try:
+        plain, _, st0 = ds.render(200, 300, 456, 428)
+        device.set_counting(True)
+        try:
+            counted, _, st1 = ds.render(200, 300, 456, 428)
+        finally:
+            device.set_counting(False)
+    finally:
+        ds.close()
+        _aa_settings(s, **old)
+    assert st0["kd_nodes_visited"] == 0 and st0["tris_tested"] == 0
+    assert st1["rays"] == st0["rays"] and np.abs(counted - plain).max() <= SUM_ORDER_TOL
+    assert st1["kd_nodes_visited"] > st1["rays"] and 0 < st1["tris_tested"] < st1["kd_nodes_visited"]
+
+
 def test_quantize_kernel_matches_convert_to_8bit():
     import torch
     rng = np.random.default_rng(3)
