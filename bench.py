@@ -197,6 +197,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "trace_kernel", "kernel_ms": kernel_ms, "launches_per_step": 3,
+                         "launch_avg_ms": kernel_ms / 3.0,   # = rocprofv3's AverageNs of trace_kernel<false> in the --frames-in-flight 1 trace
                          "note": "one frame = 3 launches of trace_kernel (pixels, then two passes over handed-over ray tasks, usually empty); kernel_ms, achieved and traffic are per frame = the sum over the three, measured on launches that run alone (a separate untimed loop after the timed region; rocprofv3 of `bench.py --frames-in-flight 1`: TotalDurationNs / frames); the timed region overlaps frames, so ms_per_step can be below kernel_ms",
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_visit_and_test": [per_visit, per_test],
                          "kd_nodes_visited": cstats["kd_nodes_visited"], "tris_tested": cstats["tris_tested"]},

@@ -263,6 +263,20 @@ int qd_antialias(qd_scene* scene, const qd_camera* camera, const qd_settings* se
 int qd_antialias_device(qd_scene* scene, const qd_camera* camera, const qd_settings* settings,
                         float* rgb_dev, qd_stats* stats);
 
+/* The same pass in three steps, so that the taps -- the only expensive part -- can be traced by several GPUs
+ * (the pass needs the whole first-pass frame, so it runs after the gather).  Every rank holding the
+ * assembled first-pass frame calls qd_aa_begin_device (mark + list; the list depends on the frame only, so all ranks
+ * get the same one; *n_listed = pixels whose four taps are to be traced, 0 with showAA or when nothing is marked),
+ * then traces ITS slice of the list with qd_aa_trace_part_async (taps_dev receives n_pixels * 4 * 3 floats, tap-major
+ * per pixel; enqueue only), the slices are gathered, and the rank that keeps the frame calls qd_aa_end_device with all
+ * n_listed * 12 floats (combine, bucket-ordered mark / replace rule, frame updated in place).  A rank that does not keep
+ * the frame ends its plan with qd_aa_end_device(scene, settings, NULL, NULL).  qd_antialias_device is exactly
+ * begin + one part covering the whole list + end.  Replaces: src/main.cpp:106-153 as above. */
+int qd_aa_begin_device(qd_scene* scene, const qd_settings* settings, const float* rgb_dev, uint32_t* n_listed);
+int qd_aa_trace_part_async(qd_scene* scene, const qd_camera* camera, const qd_settings* settings,
+                           uint32_t first_pixel, uint32_t n_pixels, float* taps_dev, qd_stats* stats_dev, void* hip_stream);
+int qd_aa_end_device(qd_scene* scene, const qd_settings* settings, const float* taps_dev, float* rgb_dev);
+
 /* Same as qd_render but every output pointer is DEVICE memory and the call only
  * enqueues work on `hip_stream` (a hipStream_t passed as void*; NULL = default
  * stream).  Pixels are selected by tile ownership instead of a rectangle:

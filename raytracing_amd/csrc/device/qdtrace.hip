@@ -8,6 +8,7 @@
 // (SURVEY.md section 3C), so recursion unrolls into weights.  Waves pull 8x8-pixel units from
 // eight work queues (one per XCD label, with stealing) so that each XCD's private L2 sees one
 // contiguous image region and therefore one region of the KD-tree.
+#include <hipcub/hipcub.hpp>
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -756,6 +757,15 @@ __global__ void aa_mark_kernel(const float* __restrict__ first, int W, int H, in
     slot[(size_t)y * W + x] = sl;
 }
 
+// The list comes out of aa_mark_kernel in the order the atomics landed; sorted by (y, x) it is a function of the frame
+// alone, so that every rank of a multi-GPU pass cuts the same slices.  This re-derives the pixel -> list index map.
+__global__ void aa_slot_kernel(const uint32_t* __restrict__ list, uint32_t n, int W, int32_t* __restrict__ slot) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t xy = list[i];
+    slot[(size_t)(xy >> 16) * W + (xy & 0xffffu)] = (int32_t)i;
+}
+
 __global__ void aa_combine_kernel(const float* __restrict__ first, const float* __restrict__ taps, const uint32_t* __restrict__ list,
                                   uint32_t n, int W, float* __restrict__ aa) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -816,8 +826,19 @@ struct WorkSet {
     uint64_t last_use = 0;
 };
 
+// State of an AA pass between its three steps (mark / trace the taps / combine + resolve), see aa_begin.
+struct AaPlan {
+    int W = 0, H = 0;
+    float* first = nullptr;        // copy of the first-pass frame
+    int32_t* slot = nullptr;       // per pixel: index in the list or -1
+    uint32_t* list = nullptr;      // x | y << 16 of every pixel whose taps are traced (+ one word for the count)
+    uint32_t n_list = 0;
+    bool traced = false;           // false: nothing listed, or showAA (marks are painted, no taps)
+};
+
 struct qd_scene {
     DScene d;
+    AaPlan aa;
     std::vector<void*> allocs;
     uint32_t n_lanes = 0;
     WorkSet sets[kMaxWorkSets];
@@ -1139,6 +1160,7 @@ extern "C" void qd_scene_destroy(qd_scene* s) {
     if (!s) return;
     for (void* p : s->allocs) (void)hipFree(p);
     for (auto& w : s->sets) free_set(w);
+    for (void* p : {(void*)s->aa.first, (void*)s->aa.slot, (void*)s->aa.list}) if (p) (void)hipFree(p);
     if (s->stats) (void)hipFree(s->stats);
     if (s->error_flag) (void)hipFree(s->error_flag);
     delete s;
@@ -1219,65 +1241,91 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
 
 
 namespace {
-// rgb: host buffer with `pitch`, or (rgb_dev) a contiguous W x H x 3 device buffer; in place either way
-int antialias_impl(qd_scene* s, const qd_camera* cam, const qd_settings* st, float* rgb, size_t pitch, float* rgb_dev, qd_stats* stats) {
-    if (!s || !cam || !st || !(rgb || rgb_dev)) return set_err("qd_antialias: null argument");
+#define TRY3(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); aa_free(s); return -1; } } while (0)
+
+void aa_free(qd_scene* s) {
+    AaPlan& a = s->aa;
+    for (void* p : {(void*)a.first, (void*)a.slot, (void*)a.list}) if (p) (void)hipFree(p);
+    a = AaPlan();
+}
+
+// Step 1 of the AA pass: copy the first-pass frame (device, contiguous) into the handle, mark, list.
+int aa_begin(qd_scene* s, const qd_settings* st, const float* rgb_dev, uint32_t* n_listed) {
     const int W = st->frame_width, H = st->frame_height;
     if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return set_err("qd_antialias: frame size out of range");
-    if (!rgb_dev && pitch < (size_t)W * 3) return set_err("qd_antialias: row pitch smaller than the frame");
+    aa_free(s);
+    AaPlan& a = s->aa;
     const size_t npx = (size_t)W * H;
-    float *d_first = nullptr, *d_a = nullptr, *d_b = nullptr, *d_taps = nullptr, *d_aa = nullptr;
-    int32_t* d_slot = nullptr; uint32_t* d_list = nullptr; uint32_t* d_count = nullptr; int* d_changed = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    auto cleanup = [&]() {
-        for (void* p : {(void*)d_first, (void*)d_a, (void*)d_b, (void*)d_taps, (void*)d_aa, (void*)d_slot, (void*)d_list, (void*)d_count, (void*)d_changed})
-            if (p) (void)hipFree(p);
-        if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
-    };
+    uint32_t* d_count = nullptr;
+    TRY3(hipMalloc((void**)&a.first, npx * 3 * sizeof(float)));
+    TRY3(hipMalloc((void**)&a.slot, npx * sizeof(int32_t)));
+    TRY3(hipMalloc((void**)&a.list, (npx + 1) * sizeof(uint32_t)));        // last word: the count
+    d_count = a.list + npx;
+    TRY3(hipMemcpy(a.first, rgb_dev, npx * 3 * sizeof(float), hipMemcpyDeviceToDevice));
+    TRY3(hipMemset(d_count, 0, sizeof(uint32_t)));
+    TRY3(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
+    const dim3 blk(64), grd((unsigned)(W + 63) / 64, (unsigned)H);
+    hipLaunchKernelGGL(aa_mark_kernel, grd, blk, 0, nullptr, a.first, W, H, st->want_adaptive_aa, st->aa_threshold, a.slot, a.list, d_count);
+    TRY3(hipMemcpy(&a.n_list, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (a.n_list > 1) {
+        uint32_t* sorted = nullptr; void* tmp = nullptr; size_t tmp_bytes = 0;
+        TRY3(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, a.list, sorted, (int)a.n_list));
+        hipError_t e1 = hipMalloc((void**)&sorted, (size_t)a.n_list * sizeof(uint32_t));
+        hipError_t e2 = e1 == hipSuccess ? hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1) : e1;
+        hipError_t e3 = e2 == hipSuccess ? hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, a.list, sorted, (int)a.n_list) : e2;
+        if (e3 == hipSuccess) e3 = hipMemcpy(a.list, sorted, (size_t)a.n_list * sizeof(uint32_t), hipMemcpyDeviceToDevice);
+        if (sorted) (void)hipFree(sorted); if (tmp) (void)hipFree(tmp);
+        TRY3(e3);
+        hipLaunchKernelGGL(aa_slot_kernel, dim3((a.n_list + 255u) / 256u), dim3(256), 0, nullptr, a.list, a.n_list, W, a.slot);
+        TRY3(hipGetLastError());
+    }
+    a.W = W; a.H = H;
+    a.traced = a.n_list && !st->show_aa;
+    if (n_listed) *n_listed = a.traced ? a.n_list : 0u;
+    return 0;
+}
+
+// Step 2: the four taps of listed pixels [first_pixel, first_pixel + n_pixels) -> taps_dev[n_pixels * 4 * 3] (enqueue only).
+int aa_trace(qd_scene* s, const qd_camera* cam, const qd_settings* st, uint32_t first_pixel, uint32_t n_pixels, float* taps_dev,
+             unsigned long long* stats_dev, hipStream_t stream) {
+    const AaPlan& a = s->aa;
+    if (!a.first || st->frame_width != a.W || st->frame_height != a.H) return set_err("qd_aa_trace_part_async: no plan for this frame (qd_aa_begin_device first)");
+    if (!a.traced || n_pixels == 0) return 0;
+    if ((uint64_t)first_pixel + n_pixels > a.n_list) return set_err("qd_aa_trace_part_async: pixel range outside the list");
+    Params P; fill_common(P, cam, st);
+    P.mode = 2; P.aa_pixels = a.list + first_pixel; P.n_samples = n_pixels * 4u;
+    P.n_units = (P.n_samples + kUnitPx - 1u) / kUnitPx;
+    P.rgb = taps_dev; P.rgb_floats = (size_t)P.n_samples * 3; P.stats = stats_dev;
+    return launch(s, P, st->max_trace_depth, stream);
+}
+
+// Step 3: combine first-pass colour and taps, apply the bucket-ordered mark / replace rule, write the frame.
+int aa_end(qd_scene* s, const qd_settings* st, const float* taps_dev, float* rgb_dev) {
+    AaPlan& a = s->aa;
+    const int W = a.W, H = a.H;
+    if (!a.first || st->frame_width != W || st->frame_height != H) return set_err("qd_aa_end_device: no plan for this frame (qd_aa_begin_device first)");
+    if (a.traced && !taps_dev) return set_err("qd_aa_end_device: taps missing");
+    const size_t npx = (size_t)W * H;
+    float *d_a = nullptr, *d_b = nullptr, *d_aa = nullptr; int* d_changed = nullptr;
+    auto cleanup = [&]() { for (void* p : {(void*)d_a, (void*)d_b, (void*)d_aa, (void*)d_changed}) if (p) (void)hipFree(p); aa_free(s); };
 #define TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return -1; } } while (0)
-    TRY2(hipMalloc((void**)&d_first, npx * 3 * sizeof(float)));
     TRY2(hipMalloc((void**)&d_a, npx * 3 * sizeof(float)));
     TRY2(hipMalloc((void**)&d_b, npx * 3 * sizeof(float)));
-    TRY2(hipMalloc((void**)&d_slot, npx * sizeof(int32_t)));
-    TRY2(hipMalloc((void**)&d_list, npx * sizeof(uint32_t)));
-    TRY2(hipMalloc((void**)&d_count, sizeof(uint32_t)));
     TRY2(hipMalloc((void**)&d_changed, sizeof(int)));
-    if (rgb_dev) TRY2(hipMemcpy(d_first, rgb_dev, npx * 3 * sizeof(float), hipMemcpyDeviceToDevice));
-    else TRY2(hipMemcpy2D(d_first, (size_t)W * 3 * sizeof(float), rgb, pitch * sizeof(float), (size_t)W * 3 * sizeof(float), H, hipMemcpyHostToDevice));
-    TRY2(hipMemset(d_count, 0, sizeof(uint32_t)));
-    TRY2(hipMemsetAsync(s->stats, 0, 24 * sizeof(unsigned long long), nullptr));
-    TRY2(hipMemsetAsync(s->stats + 16, 0xff, sizeof(unsigned long long), nullptr)); TRY2(hipMemsetAsync(s->stats + 19, 0xff, sizeof(unsigned long long), nullptr));
-    TRY2(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
-    const dim3 blk(64), grd((unsigned)(W + 63) / 64, (unsigned)H);
-    hipLaunchKernelGGL(aa_mark_kernel, grd, blk, 0, nullptr, d_first, W, H, st->want_adaptive_aa, st->aa_threshold, d_slot, d_list, d_count);
-    uint32_t n_list = 0;
-    TRY2(hipMemcpy(&n_list, d_count, sizeof n_list, hipMemcpyDeviceToHost));
-    float ms = 0;
-    if (n_list && !st->show_aa) {
-        TRY2(hipMalloc((void**)&d_taps, (size_t)n_list * 4 * 3 * sizeof(float)));
-        TRY2(hipMalloc((void**)&d_aa, (size_t)n_list * 3 * sizeof(float)));
-        Params P; fill_common(P, cam, st);
-        P.mode = 2; P.aa_pixels = d_list; P.n_samples = n_list * 4u;
-        P.n_units = (P.n_samples + kUnitPx - 1u) / kUnitPx;
-        P.rgb = d_taps; P.rgb_floats = (size_t)P.n_samples * 3; P.stats = s->stats;
-        TRY2(hipEventCreate(&e0)); TRY2(hipEventCreate(&e1));
-        TRY2(hipEventRecord(e0, nullptr));
-        if (launch(s, P, st->max_trace_depth, nullptr)) { cleanup(); return -1; }
-        TRY2(hipEventRecord(e1, nullptr));
-        hipLaunchKernelGGL(aa_combine_kernel, dim3((n_list + 255u) / 256u), dim3(256), 0, nullptr, d_first, d_taps, d_list, n_list, W, d_aa);
-        TRY2(hipEventSynchronize(e1));
-        TRY2(hipEventElapsedTime(&ms, e0, e1));
+    if (a.traced) {
+        TRY2(hipMalloc((void**)&d_aa, (size_t)a.n_list * 3 * sizeof(float)));
+        hipLaunchKernelGGL(aa_combine_kernel, dim3((a.n_list + 255u) / 256u), dim3(256), 0, nullptr, a.first, taps_dev, a.list, a.n_list, W, d_aa);
     }
     // fixed point of the bucket-ordered rule; iteration k is exact for every pixel whose chain of earlier-bucket
     // neighbours is shorter than k, so the bucket count bounds the loop
-    TRY2(hipMemcpy(d_a, d_first, npx * 3 * sizeof(float), hipMemcpyDeviceToDevice));
+    TRY2(hipMemcpy(d_a, a.first, npx * 3 * sizeof(float), hipMemcpyDeviceToDevice));
     float *cur = d_a, *next = d_b;
+    const dim3 blk(64), grd((unsigned)(W + 63) / 64, (unsigned)H);
     const int max_iter = ((W - 1) / 48 + 1) * ((H - 1) / 48 + 1) + 2;
-    int iter = 0;
-    for (;; ++iter) {
+    for (int iter = 0;; ++iter) {
         if (iter > max_iter) { cleanup(); return set_err("qd_antialias: mark / replace rule did not settle"); }
         TRY2(hipMemset(d_changed, 0, sizeof(int)));
-        hipLaunchKernelGGL(aa_resolve_kernel, grd, blk, 0, nullptr, d_first, cur, next, d_aa, d_slot, W, H, st->want_adaptive_aa, st->aa_threshold,
+        hipLaunchKernelGGL(aa_resolve_kernel, grd, blk, 0, nullptr, a.first, cur, next, d_aa, a.slot, W, H, st->want_adaptive_aa, st->aa_threshold,
                            st->show_aa, st->aa_debug_color[0], st->aa_debug_color[1], st->aa_debug_color[2], d_changed, s->error_flag);
         int changed = 0;
         TRY2(hipMemcpy(&changed, d_changed, sizeof changed, hipMemcpyDeviceToHost));
@@ -1286,9 +1334,54 @@ int antialias_impl(qd_scene* s, const qd_camera* cam, const qd_settings* st, flo
     }
     int err_flag = 0;
     TRY2(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (err_flag) { cleanup(); return set_err(err_flag == 2 ? "qd_antialias: marked pixel outside the traced set" : "qd_antialias: ray queue overflow on device"); }
-    if (rgb_dev) TRY2(hipMemcpy(rgb_dev, cur, npx * 3 * sizeof(float), hipMemcpyDeviceToDevice));
-    else TRY2(hipMemcpy2D(rgb, pitch * sizeof(float), cur, (size_t)W * 3 * sizeof(float), (size_t)W * 3 * sizeof(float), H, hipMemcpyDeviceToHost));
+    if (err_flag) {
+        (void)hipMemset(s->error_flag, 0, sizeof(int));
+        cleanup();
+        return set_err(err_flag == 2 ? "qd_antialias: marked pixel outside the traced set" : "qd_antialias: ray queue overflow on device");
+    }
+    TRY2(hipMemcpy(rgb_dev, cur, npx * 3 * sizeof(float), hipMemcpyDeviceToDevice));
+    cleanup();
+#undef TRY2
+    return 0;
+}
+
+// rgb: host buffer with `pitch`, or (rgb_dev) a contiguous W x H x 3 device buffer; in place either way
+int antialias_impl(qd_scene* s, const qd_camera* cam, const qd_settings* st, float* rgb, size_t pitch, float* rgb_dev, qd_stats* stats) {
+    if (!s || !cam || !st || !(rgb || rgb_dev)) return set_err("qd_antialias: null argument");
+    const int W = st->frame_width, H = st->frame_height;
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return set_err("qd_antialias: frame size out of range");
+    if (!rgb_dev && pitch < (size_t)W * 3) return set_err("qd_antialias: row pitch smaller than the frame");
+    const size_t npx = (size_t)W * H;
+    float *d_frame = nullptr, *d_taps = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        if (d_frame) (void)hipFree(d_frame); if (d_taps) (void)hipFree(d_taps);
+        if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
+        aa_free(s);
+    };
+#define TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return -1; } } while (0)
+    float* frame = rgb_dev;
+    if (!rgb_dev) {
+        TRY2(hipMalloc((void**)&d_frame, npx * 3 * sizeof(float)));
+        TRY2(hipMemcpy2D(d_frame, (size_t)W * 3 * sizeof(float), rgb, pitch * sizeof(float), (size_t)W * 3 * sizeof(float), H, hipMemcpyHostToDevice));
+        frame = d_frame;
+    }
+    TRY2(hipMemsetAsync(s->stats, 0, 24 * sizeof(unsigned long long), nullptr));
+    TRY2(hipMemsetAsync(s->stats + 16, 0xff, sizeof(unsigned long long), nullptr)); TRY2(hipMemsetAsync(s->stats + 19, 0xff, sizeof(unsigned long long), nullptr));
+    uint32_t n_list = 0;
+    if (aa_begin(s, st, frame, &n_list)) { cleanup(); return -1; }
+    float ms = 0;
+    if (n_list) {
+        TRY2(hipMalloc((void**)&d_taps, (size_t)n_list * 4 * 3 * sizeof(float)));
+        TRY2(hipEventCreate(&e0)); TRY2(hipEventCreate(&e1));
+        TRY2(hipEventRecord(e0, nullptr));
+        if (aa_trace(s, cam, st, 0, n_list, d_taps, s->stats, nullptr)) { cleanup(); return -1; }
+        TRY2(hipEventRecord(e1, nullptr));
+        TRY2(hipEventSynchronize(e1));
+        TRY2(hipEventElapsedTime(&ms, e0, e1));
+    }
+    if (aa_end(s, st, d_taps, frame)) { cleanup(); return -1; }
+    if (!rgb_dev) TRY2(hipMemcpy2D(rgb, pitch * sizeof(float), frame, (size_t)W * 3 * sizeof(float), (size_t)W * 3 * sizeof(float), H, hipMemcpyDeviceToHost));
     if (stats) {
         unsigned long long h[16];
         TRY2(hipMemcpy(h, s->stats, sizeof h, hipMemcpyDeviceToHost));
@@ -1300,7 +1393,26 @@ int antialias_impl(qd_scene* s, const qd_camera* cam, const qd_settings* st, flo
 #undef TRY2
     return 0;
 }
+#undef TRY3
 }  // namespace
+
+extern "C" int qd_aa_begin_device(qd_scene* s, const qd_settings* st, const float* rgb_dev, uint32_t* n_listed) {
+    if (!s || !st || !rgb_dev) return set_err("qd_aa_begin_device: null argument");
+    return aa_begin(s, st, rgb_dev, n_listed);
+}
+
+extern "C" int qd_aa_trace_part_async(qd_scene* s, const qd_camera* cam, const qd_settings* st, uint32_t first_pixel, uint32_t n_pixels,
+                                      float* taps_dev, qd_stats* stats_dev, void* hip_stream) {
+    if (!s || !cam || !st || (!taps_dev && n_pixels)) return set_err("qd_aa_trace_part_async: null argument");
+    if (stats_dev) HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(qd_stats), (hipStream_t)hip_stream));
+    return aa_trace(s, cam, st, first_pixel, n_pixels, taps_dev, (unsigned long long*)stats_dev, (hipStream_t)hip_stream);
+}
+
+extern "C" int qd_aa_end_device(qd_scene* s, const qd_settings* st, const float* taps_dev, float* rgb_dev) {
+    if (!s || !st) return set_err("qd_aa_end_device: null argument");
+    if (!rgb_dev) { HIP_TRY(hipDeviceSynchronize()); aa_free(s); return 0; }     // a rank that only traced a slice drops its plan
+    return aa_end(s, st, taps_dev, rgb_dev);
+}
 
 extern "C" int qd_antialias(qd_scene* s, const qd_camera* cam, const qd_settings* st, float* rgb, size_t pitch, qd_stats* stats) {
     if (!rgb) return set_err("qd_antialias: null argument");

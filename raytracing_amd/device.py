@@ -33,6 +33,9 @@ def lib():
                                 C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, P(abi.QdStats)]
         L.qd_antialias.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_void_p, C.c_size_t, P(abi.QdStats)]
         L.qd_antialias_device.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_void_p, P(abi.QdStats)]
+        L.qd_aa_begin_device.argtypes = [C.c_void_p, P(abi.QdSettings), C.c_void_p, P(C.c_uint32)]
+        L.qd_aa_trace_part_async.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.qd_aa_end_device.argtypes = [C.c_void_p, P(abi.QdSettings), C.c_void_p, C.c_void_p]
         L.qd_render_tiles_async.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p]
         L.qd_scene_bind_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -112,6 +115,23 @@ class DeviceScene:
         stats = abi.QdStats()
         _check(lib().qd_antialias_device(self._h, C.byref(cam), C.byref(st), C.c_void_p(rgb_dev_ptr), C.byref(stats)), "qd_antialias_device")
         return stats.as_dict()
+
+    def aa_begin(self, rgb_dev_ptr, settings=None):
+        """Mark + list on the assembled first-pass frame (device); returns the number of pixels whose taps are to be traced."""
+        st = settings if settings is not None else self.host_scene.settings
+        n = C.c_uint32()
+        _check(lib().qd_aa_begin_device(self._h, C.byref(st), C.c_void_p(rgb_dev_ptr), C.byref(n)), "qd_aa_begin_device")
+        return int(n.value)
+
+    def aa_trace_part(self, first_pixel, n_pixels, taps_dev_ptr, stats_dev_ptr=None, stream=None, camera=None, settings=None):
+        st = settings if settings is not None else self.host_scene.settings
+        cam = camera if camera is not None else self.host_scene.camera
+        _check(lib().qd_aa_trace_part_async(self._h, C.byref(cam), C.byref(st), first_pixel, n_pixels, C.c_void_p(taps_dev_ptr or 0),
+                                            C.c_void_p(stats_dev_ptr or 0), C.c_void_p(stream or 0)), "qd_aa_trace_part_async")
+
+    def aa_end(self, taps_dev_ptr=None, rgb_dev_ptr=None, settings=None):
+        st = settings if settings is not None else self.host_scene.settings
+        _check(lib().qd_aa_end_device(self._h, C.byref(st), C.c_void_p(taps_dev_ptr or 0), C.c_void_p(rgb_dev_ptr or 0)), "qd_aa_end_device")
 
     def render_frame(self, camera=None, settings=None):
         """RenderScene (src/main.cpp:106-161): first pass, then the AA pass when settings.wantAA is set."""

@@ -55,11 +55,19 @@ class FrameRenderer:
         self.dscene.render_tiles_async(sl.shard.data_ptr(), self.tile, self.rank, self.world,
                                        stats_dev_ptr=sl.stats.data_ptr(), stream=stream)
 
-    def _gather_shards(self, sl):
-        """Compacted shards of every rank -> sl.gathered on rank 0 (equal sizes; RCCL sends each peer's shard straight
-        to the root over that peer's own xGMI link, not around a ring)."""
+    # The collectives, in one place (tests on a one-GPU box swap these two for host-staged gloo).
+    def _coll_gather(self, src, dst):
+        """src of every rank -> dst[r] on rank 0 (dst is None elsewhere).  RCCL sends each peer's block straight to the
+        root over that peer's own xGMI link, not around a ring."""
         import torch.distributed as dist
-        dist.gather(sl.shard, list(sl.gathered.unbind(0)) if self.rank == 0 else None, dst=0)
+        dist.gather(src, list(dst.unbind(0)) if self.rank == 0 else None, dst=0)
+
+    def _coll_broadcast(self, t):
+        import torch.distributed as dist
+        dist.broadcast(t, src=0)
+
+    def _gather_shards(self, sl):
+        self._coll_gather(sl.shard, sl.gathered)
 
     def gather(self, slot=0):
         """The one exchange step: compacted shards -> rank 0, then de-interleave."""
@@ -101,15 +109,40 @@ class FrameRenderer:
         return self.slots[slot or 0].frame
 
     def render_frame(self, antialias=None):
-        """RenderScene: every rank traces its tiles, rank 0 gathers; if settings.wantAA (or antialias=True) rank 0 then
-        runs the AA pass on the assembled frame (src/main.cpp:106-153 needs the whole first pass)."""
+        """RenderScene: every rank traces its tiles, rank 0 gathers; if settings.wantAA (or antialias=True) the AA pass
+        follows on the assembled frame (src/main.cpp:106-153 needs the whole first pass): the frame goes back out to all
+        ranks, every rank marks (same frame, same list), traces the taps of its slice of the list, rank 0 gathers the
+        taps and applies the replace rule."""
         self.render_shard()
         frame = self.gather()
         want = self.scene.settings.want_aa if antialias is None else antialias
-        if want and frame is not None:
-            torch.cuda.current_stream(self.dev).synchronize()
+        if not want:
+            return frame
+        cur = torch.cuda.current_stream(self.dev)
+        if self.world == 1:
+            cur.synchronize()
             self.dscene.antialias_device(frame.data_ptr())
-        return frame
+            return frame
+        if frame is None:
+            if getattr(self, "_aa_frame", None) is None:
+                self._aa_frame = torch.zeros((self.H, self.W, 3), dtype=torch.float32, device=self.dev)
+            frame = self._aa_frame
+        self._coll_broadcast(frame)
+        cur.synchronize()
+        n = self.dscene.aa_begin(frame.data_ptr())          # identical on every rank: a function of the frame alone
+        per = (n + self.world - 1) // self.world
+        first = min(n, self.rank * per)
+        count = min(n, first + per) - first
+        taps = torch.zeros((max(per, 1), 4, 3), dtype=torch.float32, device=self.dev)
+        self.dscene.aa_trace_part(first, count, taps.data_ptr(), stream=cur.cuda_stream)
+        all_taps = torch.zeros((self.world,) + tuple(taps.shape), dtype=torch.float32, device=self.dev) if self.rank == 0 else None
+        self._coll_gather(taps, all_taps)
+        cur.synchronize()
+        if self.rank == 0:
+            self.dscene.aa_end(all_taps.data_ptr(), frame.data_ptr())     # rank-major blocks of `per` pixels = list order
+            return frame
+        self.dscene.aa_end()
+        return None
 
     def stats_dict(self):
         v = self.stats.cpu().tolist()

@@ -378,3 +378,32 @@ def test_frames_in_flight_give_the_single_frame(load_scene):
             fr.dscene.close()
     finally:
         _aa_settings(s, **old)
+
+
+def test_aa_in_steps_equals_the_single_call(load_scene):
+    """qd_aa_begin_device + qd_aa_trace_part_async over three uneven slices + qd_aa_end_device == qd_antialias_device."""
+    import torch
+    s = load_scene("hw9/nonconvex.qdmg")
+    old = _aa_settings(s, want_aa=1, want_adaptive_aa=1, show_aa=0)
+    ds = device.DeviceScene(s)
+    try:
+        first, _, _ = ds.render()
+        whole = torch.from_numpy(first).cuda()
+        ds.antialias_device(whole.data_ptr())
+        stepped = torch.from_numpy(first).cuda()
+        n = ds.aa_begin(stepped.data_ptr())
+        assert n > 100
+        taps = torch.zeros((n, 4, 3), dtype=torch.float32, device="cuda:0")
+        cuts = [0, n // 5, n // 5, n // 2 + 3, n]                 # an empty slice among them
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ds.aa_trace_part(a, b - a, taps[a:].data_ptr() if b > a else 0)
+        torch.cuda.synchronize()
+        ds.aa_end(taps.data_ptr(), stepped.data_ptr())
+        ds.check()
+        assert np.abs(stepped.cpu().numpy() - whole.cpu().numpy()).max() <= SUM_ORDER_TOL
+        assert np.abs(whole.cpu().numpy() - first).max() > 1e-3
+        with pytest.raises(device.DeviceError, match="no plan"):
+            ds.aa_trace_part(0, 1, taps.data_ptr())              # the plan ended with aa_end
+    finally:
+        ds.close()
+        _aa_settings(s, **old)

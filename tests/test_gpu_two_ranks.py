@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, flight, out_path):
+def _worker(rank, world, port, flight, out_path, aa=False):
     import datetime
     sys.path.insert(0, ROOT)
     log = open(f"{out_path}.rank{rank}.log", "w")
@@ -38,19 +38,42 @@ def _worker(rank, world, port, flight, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     note("group up")
     s = host.Scene.load(os.path.join(ROOT, "tests", "golden", "data", "kdtree_teapot_lowres_env.qdmg"))
-    s.settings.want_aa = 0
+    if aa:
+        s = host.Scene.load(os.path.join(ROOT, "tests", "golden", "data", "hw9", "nonconvex.qdmg"))
+        s.settings.want_aa, s.settings.want_adaptive_aa, s.settings.show_aa = 1, 1, 0
+    else:
+        s.settings.want_aa = 0
     class HostGather(renderer.FrameRenderer):
-        def _gather_shards(self, sl):
-            cur = torch.cuda.current_stream(self.dev)
-            cur.synchronize()
-            mine = sl.shard.cpu()
+        def _coll_gather(self, src, dst):
+            torch.cuda.current_stream(self.dev).synchronize()
+            mine = src.cpu()
             got = [torch.zeros_like(mine) for _ in range(self.world)] if self.rank == 0 else None
             dist.gather(mine, got, dst=0)
             if self.rank == 0:
-                sl.gathered.copy_(torch.stack(got))
+                dst.copy_(torch.stack(got))
+
+        def _coll_broadcast(self, t):
+            torch.cuda.current_stream(self.dev).synchronize()
+            h = t.cpu()
+            dist.broadcast(h, src=0)
+            t.copy_(h)
 
     fr = HostGather(s, tile=32, rank=rank, world=world, local_device=0, frames_in_flight=flight)
     note("scene on device")
+    if aa:
+        frame = fr.render_frame()
+        fr.check()
+        note("aa frame complete")
+        if rank == 0:
+            ref, _ = fr.dscene.render_frame()            # qd_render + qd_antialias on this rank alone
+            first, _, _ = fr.dscene.render()
+            got = frame.cpu().numpy()
+            np.save(out_path, np.array([float(np.abs(got - ref).max()), float(np.abs(got - first).max() > 1e-3)]))
+        torch.cuda.synchronize()
+        dist.barrier()
+        dist.destroy_process_group()
+        fr.dscene.close()
+        return
     slots = [fr.submit_frame() for _ in range(2 * flight + 1)][-flight:]
     note("submitted")
     frames = [fr.wait(k) for k in slots]
@@ -66,12 +89,11 @@ def _worker(rank, world, port, flight, out_path):
     fr.dscene.close()
 
 
-@pytest.mark.parametrize("flight", [1, 3])
-def test_two_ranks_with_frames_in_flight(tmp_path, flight):
+def _run_two(tmp_path, flight, aa):
     out = str(tmp_path / "res.npy")
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, flight, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, flight, out, aa)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -83,6 +105,20 @@ def test_two_ranks_with_frames_in_flight(tmp_path, flight):
         p.join()
     assert not stuck, f"ranks did not finish; progress: {logs}"
     assert all(p.exitcode == 0 for p in procs), f"exit codes {[p.exitcode for p in procs]}; progress: {logs}"
-    worst, slots_ok = np.load(out)
+    return np.load(out)
+
+
+@pytest.mark.parametrize("flight", [1, 3])
+def test_two_ranks_with_frames_in_flight(tmp_path, flight):
+    worst, slots_ok = _run_two(tmp_path, flight, False)
     assert slots_ok == 1.0
+    assert worst <= SUM_ORDER_TOL, worst
+
+
+def test_two_ranks_share_the_aa_taps(tmp_path):
+    """wantAA on two ranks: frame gathered, sent back out, both ranks mark, each traces half of the listed pixels' taps,
+    rank 0 applies the replace rule (qd_aa_begin_device / qd_aa_trace_part_async / qd_aa_end_device) == one rank's
+    qd_render + qd_antialias."""
+    worst, changed = _run_two(tmp_path, 1, True)
+    assert changed == 1.0
     assert worst <= SUM_ORDER_TOL, worst
