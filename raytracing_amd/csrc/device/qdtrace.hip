@@ -13,6 +13,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -221,10 +222,18 @@ QD_DEV void assemble_info(const DScene& S, const qd_node& n, GHit& h, double dw,
 
 // One non-layered shader at a hit: adds its direct colour to acc and queues its rays
 // (Lambert/Phong/BlinnPhong/OrenNayar/Const/Reflection/Refraction::Shade, src/shading.cpp).
+constexpr int kMaxLayerNesting = 4;      // Layered inside Layered ...: levels below the node's own shader (qd_scene_create checks)
+__device__ QD_OUTLINE void eval_nested_layered(const DScene& S, const Params& P, const qd_shader& top, Col w, uint32_t slot, const Task& ray,
+                                               uint32_t depth, const Info& info, Col& acc, LaneQueue& q);
+
+// NESTED: a Layered shader met here (a layer that is itself Layered) goes to eval_nested_layered, which walks the inner
+// layers with an explicit stack and calls the NESTED = false copy for the leaves -- no recursion on the device.
+template <bool NESTED>
 __device__ QD_OUTLINE void eval_leaf_shader(const DScene& S, const Params& P, int si, Col w, uint32_t slot, const Task& ray, uint32_t depth,
                              const Info& info, Col& acc, LaneQueue& q) {
     const qd_shader sh = S.shaders[si];
     switch (sh.type) {
+        case QD_SH_LAYERED: if (NESTED) eval_nested_layered(S, P, sh, w, slot, ray, depth, info, acc, q); break;
         case QD_SH_CONST: acc = acc + w * ldc(sh.color); break;
         case QD_SH_LAMBERT: case QD_SH_PHONG: case QD_SH_BLINNPHONG: case QD_SH_ORENNAYAR: {
             const Col diffuse = sh.tex >= 0 ? tex_sample(S, sh.tex, info) : ldc(sh.color);
@@ -323,7 +332,34 @@ __device__ QD_OUTLINE void eval_leaf_shader(const DScene& S, const Params& P, in
             q.push(r);
             break;
         }
-        default: break;   // nested Layered is rejected by qd_scene_create
+        default: break;
+    }
+}
+
+// Layered::Shade (src/shading.cpp:260-275) for a Layered that is a layer of another one: the same suffix-product walk as
+// in the kernel, one stack frame per nesting level.  A layer's path-id slot is parent_slot * 32 + i + 1 (the oracle's rule).
+__device__ QD_OUTLINE void eval_nested_layered(const DScene& S, const Params& P, const qd_shader& top, Col w, uint32_t slot, const Task& ray,
+                                               uint32_t depth, const Info& info, Col& acc, LaneQueue& q) {
+    struct Frame { int i0, i; uint32_t slot; Col w, suffix; };
+    Frame st[kMaxLayerNesting];
+    int sp = 0;
+    st[0] = Frame{top.i0, top.i1 - 1, slot, w, mkc(1.f, 1.f, 1.f)};
+    while (sp >= 0) {
+        Frame& f = st[sp];
+        if (f.i < 0) { --sp; continue; }
+        const qd_layer l = S.layers[f.i0 + f.i];
+        Col blend = ldc(l.blend);
+        if (l.tex >= 0) blend = blend * tex_sample(S, l.tex, info);
+        const Col wl = f.w * (blend * f.suffix);
+        const uint32_t child_slot = f.slot * 32u + (uint32_t)f.i + 1u;
+        f.suffix = f.suffix * (mkc(1.f, 1.f, 1.f) - blend);
+        --f.i;
+        const qd_shader inner = S.shaders[l.shader];
+        if (inner.type == QD_SH_LAYERED) {
+            if (sp + 1 < kMaxLayerNesting) { ++sp; st[sp] = Frame{inner.i0, inner.i1 - 1, child_slot, wl, mkc(1.f, 1.f, 1.f)}; }
+        } else {
+            eval_leaf_shader<false>(S, P, l.shader, wl, child_slot, ray, depth, info, acc, q);
+        }
     }
 }
 
@@ -609,11 +645,11 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
                 const qd_layer l = S.layers[top.i0 + i];
                 Col blend = ldc(l.blend);
                 if (l.tex >= 0) blend = blend * tex_sample(S, l.tex, info);
-                eval_leaf_shader(S, P, l.shader, t.w * (blend * suffix), (uint32_t)i + 1, t, depth, info, acc, q);
+                eval_leaf_shader<true>(S, P, l.shader, t.w * (blend * suffix), (uint32_t)i + 1, t, depth, info, acc, q);
                 suffix = suffix * (mkc(1.f, 1.f, 1.f) - blend);
             }
         } else {
-            eval_leaf_shader(S, P, n.shader, t.w, 0, t, depth, info, acc, q);
+            eval_leaf_shader<true>(S, P, n.shader, t.w, 0, t, depth, info, acc, q);
         }
         t_shade += QD_STAMP() - tp2;
         } while (false);
@@ -1050,19 +1086,24 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
             default: return 0u;
         }
     };
+    // tasks one hit can queue: the leaves of the shader tree (Layered may nest, kMaxLayerNesting levels below the top)
+    std::string spawn_err;
+    std::function<bool(const qd_shader&, int, uint32_t&, uint32_t&)> tree_spawn = [&](const qd_shader& sh, int level, uint32_t& s0, uint32_t& s1) -> bool {
+        if (sh.type != QD_SH_LAYERED) { s0 += leaf_spawn(sh, false); s1 += leaf_spawn(sh, true); return true; }
+        if (level > kMaxLayerNesting) { spawn_err = "qd_scene_create: Layered shaders nested deeper than 4 levels"; return false; }
+        if (sh.i0 < 0 || sh.i1 < 0 || (uint32_t)(sh.i0 + sh.i1) > desc->n_layers) { spawn_err = "qd_scene_create: layer range out of bounds"; return false; }
+        for (int l = 0; l < sh.i1; ++l) {
+            const qd_layer& ly = desc->layers[sh.i0 + l];
+            if (ly.shader < 0 || (uint32_t)ly.shader >= desc->n_shaders || !tex_ok(ly.tex)) { spawn_err = "qd_scene_create: layer reference out of range"; return false; }
+            if (!tree_spawn(desc->shaders[ly.shader], level + 1, s0, s1)) return false;
+        }
+        return true;
+    };
     for (uint32_t i = 0; i < desc->n_shaders; ++i) {
         const qd_shader& sh = desc->shaders[i];
         if (!tex_ok(sh.tex)) return set_err("qd_scene_create: shader texture out of range");
         uint32_t s0 = 0, s1 = 0;
-        if (sh.type == QD_SH_LAYERED) {
-            if (sh.i0 < 0 || sh.i1 < 0 || (uint32_t)(sh.i0 + sh.i1) > desc->n_layers) return set_err("qd_scene_create: layer range out of bounds");
-            for (int l = 0; l < sh.i1; ++l) {
-                const qd_layer& ly = desc->layers[sh.i0 + l];
-                if (ly.shader < 0 || (uint32_t)ly.shader >= desc->n_shaders || !tex_ok(ly.tex)) return set_err("qd_scene_create: layer reference out of range");
-                if (desc->shaders[ly.shader].type == QD_SH_LAYERED) return set_err("qd_scene_create: nested Layered shaders are not supported by the device path");
-                s0 += leaf_spawn(desc->shaders[ly.shader], false); s1 += leaf_spawn(desc->shaders[ly.shader], true);
-            }
-        } else { s0 = leaf_spawn(sh, false); s1 = leaf_spawn(sh, true); }
+        if (!tree_spawn(sh, 0, s0, s1)) return set_err(spawn_err);
         spawn0 = std::max(spawn0, s0); spawn1 = std::max(spawn1, s1);
     }
     for (uint32_t i = 0; i < desc->n_nodes; ++i) {

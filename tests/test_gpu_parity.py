@@ -216,13 +216,24 @@ def test_bucket_by_bucket_render_and_cancel(load_scene):
         _aa_settings(s, **old)
 
 
-def test_nested_layered_and_csg_are_rejected_loudly(tmp_path):
-    p = tmp_path / "n.qdmg"
-    p.write_text("Camera c {\n position (0,0,-5)\n}\nSphere s {\n}\nConst k {\n}\nLayered a {\n layer k (1,1,1)\n}\n"
-                 "Layered b {\n layer a (1,1,1)\n}\nNode n {\n geometry s\n shader b\n}\n")
-    s = host.Scene.load(str(p))
-    with pytest.raises(device.DeviceError, match="nested Layered"):
-        device.DeviceScene(s)
+def test_nested_layered_matches_oracle_and_too_deep_is_rejected(load_scene, tmp_path):
+    """Layered inside Layered (three levels, glossy + Fresnel inside): the device's explicit-stack walk against the
+    oracle's recursion, path ids of the inner layers included (the glossy samples would differ otherwise).  Nesting
+    beyond the device's stack is refused at scene creation, loudly."""
+    s = load_scene("nested_layered.qdmg")
+    ds = device.DeviceScene(s)
+    try:
+        r = compare(s, ds, 0, 0, s.settings.frame_width, s.settings.frame_height)
+    finally:
+        ds.close()
+    assert r["id_mismatch"] == 0 and r["dist_mismatch"] == 0
+    assert r["bad_colour"] == 0, (r["bad_colour"], r["max_err"])
+    assert r["gpu"]["rays"] == r["cpu"]["rays"]
+    p = tmp_path / "deep.qdmg"
+    layers = "".join(f"Layered l{i} {{\n layer l{i - 1} (1,1,1)\n}}\n" for i in range(1, 7))
+    p.write_text("Camera c {\n position (0,0,-5)\n}\nSphere s {\n}\nConst l0 {\n}\n" + layers + "Node n {\n geometry s\n shader l6\n}\n")
+    with pytest.raises(device.DeviceError, match="nested deeper"):
+        device.DeviceScene(host.Scene.load(str(p)))
 
 
 # ---------------------------------------------------------------- anti-aliasing pass (src/main.cpp:58-83, 106-153)
