@@ -603,9 +603,12 @@ QD_DEV bool csg_intersect(const DScene& S, const qd_geom& g, const DV& start, co
     return false;
 }
 
-// Analytic geometry (primitives and CSG of primitives): full hit record.
+// Analytic geometry (primitives and CSG of primitives): full hit record.  CSG / PRIMS: whether the scene holds CSG nodes /
+// primitives other than planes (see trace_nodes' GEOM mask); what it does not hold is not compiled into the caller.
+template <bool CSG, bool PRIMS>
 QD_DEV bool analytic_intersect(const DScene& S, const qd_geom& g, const DV& start, const DV& dir, GHit& out) {
-    if (g.type == QD_GEOM_CSG) return csg_intersect(S, g, start, dir, out);
+    if (CSG && g.type == QD_GEOM_CSG) return csg_intersect(S, g, start, dir, out);
+    if (!PRIMS) return plane_intersect(g, start, dir, out);
     return prim_intersect(g, start, dir, out);
 }
 

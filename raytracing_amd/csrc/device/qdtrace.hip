@@ -138,7 +138,12 @@ struct LaneQueue {
 //  * shadow ray: product of shadowTransparency over the nodes whose closest hit is nearer than the light
 //    (ShadingHelper::GetShadowTransparency, src/shadinghelper.cpp:20-40).  Once the product is exactly 0
 //    no later factor can change it, so the node loop stops there.
-template <bool STATS>
+// GEOM: which geometry code this copy of the node loop contains besides meshes and planes (kGeomHf: heightfield DDA,
+// kGeomCsg: CSG walk, kGeomPrim: sphere / cube / regular polygon).  qd_scene_create derives the mask from the scene and
+// launch() picks the kernel: what a scene does not hold is compiled out -- smaller live ranges, fewer spills around the
+// mesh query (the 10 M triangle scene, meshes + a plane: +9.5 %).
+constexpr int kGeomHf = 1, kGeomCsg = 2, kGeomPrim = 4, kGeomAll = 7;
+template <bool STATS, int GEOM>
 __device__ QD_OUTLINE int trace_nodes(const DScene& S, const DV& o, const DV& d, bool shadow, double target,
                        float& transp, double& best_dw, GHit& hit, Counters& cnt) {
     int best_node = -1;
@@ -175,12 +180,12 @@ __device__ QD_OUTLINE int trace_nodes(const DScene& S, const DV& o, const DV& d,
             cnt.t_desc += mh.n_nodes; cnt.t_leaf += mh.n_tris;
 #endif
             cnt.t_b += QD_STAMP() - ta1;
-        } else if (g.type == QD_GEOM_HEIGHTFIELD) {
+        } else if ((GEOM & kGeomHf) && g.type == QD_GEOM_HEIGHTFIELD) {
             if (final_pass) { hf_finish(S, g.a, r.o, r.d, w_dist, hit); break; }
             got = hf_intersect<STATS>(S, g.a, r.o, r.d, dist, cnt.kd_nodes, cnt.tris);
         } else {
             GHit h;
-            got = analytic_intersect(S, g, r.o, r.d, h);
+            got = analytic_intersect<(GEOM & kGeomCsg) != 0, (GEOM & kGeomPrim) != 0>(S, g, r.o, r.d, h);
             cnt.t_c += QD_STAMP() - ta1;
             if (final_pass) { hit = h; break; }
             dist = h.dist;
@@ -453,7 +458,7 @@ QD_DEV PixelSlot map_pixel(const Params& P, uint32_t unit, uint32_t p) {
 
 // Persistent lanes: a lane that finishes its pixel immediately takes the next pixel of the wave's
 // current 8x8 unit (or of a freshly fetched unit), so no lane waits for the slowest pixel of a tile.
-template <bool STATS>
+template <bool STATS, int GEOM>
 __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene S, const Params P) {
     const uint32_t lane = threadIdx.x;
     const size_t gl = (size_t)blockIdx.x * 64 + lane;
@@ -616,7 +621,7 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
         GHit h; double dw; float transp;
         const unsigned long long tp1 = QD_STAMP();
         t_sched += tp1 - tp0;
-        const int node = trace_nodes<STATS>(S, t.o, t.d, shadow, t.aux0, transp, dw, h, cnt);
+        const int node = trace_nodes<STATS, GEOM>(S, t.o, t.d, shadow, t.aux0, transp, dw, h, cnt);
         const unsigned long long tp2 = QD_STAMP();
         t_trace += tp2 - tp1;
         if (shadow) {
@@ -882,6 +887,7 @@ struct qd_scene {
     unsigned long long* stats = nullptr; // 8 counters
     int* error_flag = nullptr;
     uint32_t spawn0 = 1, spawn1 = 1;     // tasks queued per hit at depth 0 / deeper
+    int geom_mask = 7;                   // kGeomHf | kGeomCsg | kGeomPrim as present in the scene: selects the kernel copy
     uint64_t kd_nodes = 0, kd_refs = 0, kd_leaves = 0, kd_max_leaf = 0;   // device tree after refinement
 };
 
@@ -978,8 +984,11 @@ int launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream) {
         P.grace = pass == kPasses - 1 ? 0xffffffffu : kGrace;
         // later passes usually find an empty list; a launch costs ~45 ns per wave (scratch set-up), so they start fewer waves
         const uint32_t grid = pass == 0 ? (P.n_units < max_blocks ? (P.n_units ? P.n_units : 1) : max_blocks) : (max_blocks + kLaterPassDiv - 1) / kLaterPassDiv;
-        if (g_counting) hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(64), 0, stream, s->d, P);
-        else hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(64), 0, stream, s->d, P);
+        using Kernel = void (*)(const DScene, const Params);
+        static const Kernel by_geom[8] = {trace_kernel<false, 0>, trace_kernel<false, 1>, trace_kernel<false, 2>, trace_kernel<false, 3>,
+                                          trace_kernel<false, 4>, trace_kernel<false, 5>, trace_kernel<false, 6>, trace_kernel<false, 7>};
+        const Kernel kernel = g_counting ? trace_kernel<true, kGeomAll> : by_geom[s->geom_mask & kGeomAll];   // counting: one copy, all code
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, stream, s->d, P);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(w->idle, stream));
@@ -1184,6 +1193,16 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     d.env_present = desc->env_present; d.env_bilinear = desc->env_bilinear;
     for (int f = 0; f < 6; ++f) d.env_faces[f] = desc->env_faces[f];
     s->spawn0 = spawn0; s->spawn1 = spawn1;
+    s->geom_mask = 0;
+    for (uint32_t i = 0; i < desc->n_geoms; ++i) {
+        const int t = desc->geoms[i].type;
+        if (t == QD_GEOM_HEIGHTFIELD) s->geom_mask |= kGeomHf;
+        else if (t == QD_GEOM_CSG) s->geom_mask |= kGeomCsg;
+        else if (t != QD_GEOM_MESH && t != QD_GEOM_PLANE) s->geom_mask |= kGeomPrim;
+    }
+#ifdef QD_NO_GEOM_MASK
+    s->geom_mask = kGeomAll;
+#endif
     s->n_lanes = (uint32_t)(g_num_cu > 0 ? g_num_cu : 256) * kWavesPerCU * 64u;
     if (!rc && hipMalloc((void**)&s->stats, (24 + 6 * 4096) * sizeof(unsigned long long)) != hipSuccess) rc = set_err("hipMalloc(stats) failed");
     if (!rc && hipMalloc((void**)&s->error_flag, sizeof(int)) != hipSuccess) rc = set_err("hipMalloc(error flag) failed");

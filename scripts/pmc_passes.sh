@@ -20,7 +20,7 @@ res = collections.defaultdict(dict)
 for f in glob.glob(out + "/*/*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "trace_kernel<false>" not in k: continue
+        if "trace_kernel<false" not in k: continue
         res[row["Counter_Name"]].setdefault("vals", []).append(float(row["Counter_Value"]))
 LAUNCHES_PER_FRAME = 3   # one frame = 3 launches of trace_kernel (launch() in qdtrace.hip); counters are summed per frame
 summary = {c: sum(v["vals"]) / (len(v["vals"]) / LAUNCHES_PER_FRAME) for c, v in res.items()}
