@@ -43,8 +43,12 @@ QD_DEV Col bitmap_helper_color(const DScene& S, const qd_texture& t, double u, d
     return bmp_pixel(S, b, (unsigned)x % width, (unsigned)y % height);
 }
 
+// RICH = false: the scene holds only constant, checker and Fresnel textures (qd_scene_create checks); the Mandelbrot
+// loop, the procedural sines and the bitmap fetches are not compiled into that copy of the caller.
+template <bool RICH>
 QD_DEV Col tex_sample(const DScene& S, int ti, const Info& info) {
     const qd_texture t = S.textures[ti];
+    if (!RICH && t.type != QD_TEX_CONST && t.type != QD_TEX_CHECKER && t.type != QD_TEX_FRESNEL) return mkc(0, 0, 0);
     switch (t.type) {
         case QD_TEX_CONST: return ldc(t.color1);
         case QD_TEX_CHECKER: {

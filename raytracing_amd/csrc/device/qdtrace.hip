@@ -209,8 +209,9 @@ __device__ QD_OUTLINE int trace_nodes(const DScene& S, const DV& o, const DV& d,
 }
 
 // World-space IntersectionInfo of the winning hit (src/geometry.cpp:331-338).
+template <bool RICH>
 QD_DEV void assemble_info(const DScene& S, const qd_node& n, GHit& h, double dw, const DV& ray_dir, Info& info) {
-    const bool want_dnd = n.bump_tex >= 0;
+    const bool want_dnd = RICH && n.bump_tex >= 0;
     DV dndx = mk(0, 0, 0), dndy = mk(0, 0, 0);
     if (h.tri >= 0) mesh_finish(S, h, dndx, dndy, want_dnd);
     else if (h.dnd == 1) { dndx = mk(1, 0, 0); dndy = mk(0, 0, 1); }
@@ -228,20 +229,21 @@ QD_DEV void assemble_info(const DScene& S, const qd_node& n, GHit& h, double dw,
 // One non-layered shader at a hit: adds its direct colour to acc and queues its rays
 // (Lambert/Phong/BlinnPhong/OrenNayar/Const/Reflection/Refraction::Shade, src/shading.cpp).
 constexpr int kMaxLayerNesting = 4;      // Layered inside Layered ...: levels below the node's own shader (qd_scene_create checks)
+template <bool RICH>
 __device__ QD_OUTLINE void eval_nested_layered(const DScene& S, const Params& P, const qd_shader& top, Col w, uint32_t slot, const Task& ray,
                                                uint32_t depth, const Info& info, Col& acc, LaneQueue& q);
 
 // NESTED: a Layered shader met here (a layer that is itself Layered) goes to eval_nested_layered, which walks the inner
 // layers with an explicit stack and calls the NESTED = false copy for the leaves -- no recursion on the device.
-template <bool NESTED>
+template <bool NESTED, bool RICH>
 __device__ QD_OUTLINE void eval_leaf_shader(const DScene& S, const Params& P, int si, Col w, uint32_t slot, const Task& ray, uint32_t depth,
                              const Info& info, Col& acc, LaneQueue& q) {
     const qd_shader sh = S.shaders[si];
     switch (sh.type) {
-        case QD_SH_LAYERED: if (NESTED) eval_nested_layered(S, P, sh, w, slot, ray, depth, info, acc, q); break;
+        case QD_SH_LAYERED: if (NESTED) eval_nested_layered<RICH>(S, P, sh, w, slot, ray, depth, info, acc, q); break;
         case QD_SH_CONST: acc = acc + w * ldc(sh.color); break;
         case QD_SH_LAMBERT: case QD_SH_PHONG: case QD_SH_BLINNPHONG: case QD_SH_ORENNAYAR: {
-            const Col diffuse = sh.tex >= 0 ? tex_sample(S, sh.tex, info) : ldc(sh.color);
+            const Col diffuse = sh.tex >= 0 ? tex_sample<RICH>(S, sh.tex, info) : ldc(sh.color);
             acc = acc + w * (diffuse * ldc(P.ambient));
             for (uint32_t li = 0; li < S.n_lights; ++li) {
                 const qd_light L = S.lights[li];
@@ -343,6 +345,7 @@ __device__ QD_OUTLINE void eval_leaf_shader(const DScene& S, const Params& P, in
 
 // Layered::Shade (src/shading.cpp:260-275) for a Layered that is a layer of another one: the same suffix-product walk as
 // in the kernel, one stack frame per nesting level.  A layer's path-id slot is parent_slot * 32 + i + 1 (the oracle's rule).
+template <bool RICH>
 __device__ QD_OUTLINE void eval_nested_layered(const DScene& S, const Params& P, const qd_shader& top, Col w, uint32_t slot, const Task& ray,
                                                uint32_t depth, const Info& info, Col& acc, LaneQueue& q) {
     struct Frame { int i0, i; uint32_t slot; Col w, suffix; };
@@ -354,7 +357,7 @@ __device__ QD_OUTLINE void eval_nested_layered(const DScene& S, const Params& P,
         if (f.i < 0) { --sp; continue; }
         const qd_layer l = S.layers[f.i0 + f.i];
         Col blend = ldc(l.blend);
-        if (l.tex >= 0) blend = blend * tex_sample(S, l.tex, info);
+        if (l.tex >= 0) blend = blend * tex_sample<RICH>(S, l.tex, info);
         const Col wl = f.w * (blend * f.suffix);
         const uint32_t child_slot = f.slot * 32u + (uint32_t)f.i + 1u;
         f.suffix = f.suffix * (mkc(1.f, 1.f, 1.f) - blend);
@@ -363,7 +366,7 @@ __device__ QD_OUTLINE void eval_nested_layered(const DScene& S, const Params& P,
         if (inner.type == QD_SH_LAYERED) {
             if (sp + 1 < kMaxLayerNesting) { ++sp; st[sp] = Frame{inner.i0, inner.i1 - 1, child_slot, wl, mkc(1.f, 1.f, 1.f)}; }
         } else {
-            eval_leaf_shader<false>(S, P, l.shader, wl, child_slot, ray, depth, info, acc, q);
+            eval_leaf_shader<false, RICH>(S, P, l.shader, wl, child_slot, ray, depth, info, acc, q);
         }
     }
 }
@@ -458,7 +461,8 @@ QD_DEV PixelSlot map_pixel(const Params& P, uint32_t unit, uint32_t p) {
 
 // Persistent lanes: a lane that finishes its pixel immediately takes the next pixel of the wave's
 // current 8x8 unit (or of a freshly fetched unit), so no lane waits for the slowest pixel of a tile.
-template <bool STATS, int GEOM>
+// RICH: bitmap / Mandelbrot / procedural textures or bump maps present (see tex_sample); GEOM: see trace_nodes.
+template <bool STATS, int GEOM, bool RICH>
 __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene S, const Params P) {
     const uint32_t lane = threadIdx.x;
     const size_t gl = (size_t)blockIdx.x * 64 + lane;
@@ -639,8 +643,8 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
         }
         const qd_node& n = S.nodes[node];
         Info info;
-        assemble_info(S, n, h, dw, t.d, info);
-        if (n.bump_tex >= 0) tex_modify_normal(S, n.bump_tex, info);
+        assemble_info<RICH>(S, n, h, dw, t.d, info);
+        if (RICH && n.bump_tex >= 0) tex_modify_normal(S, n.bump_tex, info);
         const qd_shader top = S.shaders[n.shader];
         if (top.type == QD_SH_LAYERED) {
             // Layered::Shade (src/shading.cpp:260-275): result = b*layer + (1-b)*result, i.e. layer i carries
@@ -649,12 +653,12 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
             for (int i = top.i1 - 1; i >= 0; --i) {
                 const qd_layer l = S.layers[top.i0 + i];
                 Col blend = ldc(l.blend);
-                if (l.tex >= 0) blend = blend * tex_sample(S, l.tex, info);
-                eval_leaf_shader<true>(S, P, l.shader, t.w * (blend * suffix), (uint32_t)i + 1, t, depth, info, acc, q);
+                if (l.tex >= 0) blend = blend * tex_sample<RICH>(S, l.tex, info);
+                eval_leaf_shader<true, RICH>(S, P, l.shader, t.w * (blend * suffix), (uint32_t)i + 1, t, depth, info, acc, q);
                 suffix = suffix * (mkc(1.f, 1.f, 1.f) - blend);
             }
         } else {
-            eval_leaf_shader<true>(S, P, n.shader, t.w, 0, t, depth, info, acc, q);
+            eval_leaf_shader<true, RICH>(S, P, n.shader, t.w, 0, t, depth, info, acc, q);
         }
         t_shade += QD_STAMP() - tp2;
         } while (false);
@@ -888,6 +892,7 @@ struct qd_scene {
     int* error_flag = nullptr;
     uint32_t spawn0 = 1, spawn1 = 1;     // tasks queued per hit at depth 0 / deeper
     int geom_mask = 7;                   // kGeomHf | kGeomCsg | kGeomPrim as present in the scene: selects the kernel copy
+    bool rich = true;                    // bitmap / Mandelbrot / procedural textures or bump maps present
     uint64_t kd_nodes = 0, kd_refs = 0, kd_leaves = 0, kd_max_leaf = 0;   // device tree after refinement
 };
 
@@ -985,9 +990,12 @@ int launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream) {
         // later passes usually find an empty list; a launch costs ~45 ns per wave (scratch set-up), so they start fewer waves
         const uint32_t grid = pass == 0 ? (P.n_units < max_blocks ? (P.n_units ? P.n_units : 1) : max_blocks) : (max_blocks + kLaterPassDiv - 1) / kLaterPassDiv;
         using Kernel = void (*)(const DScene, const Params);
-        static const Kernel by_geom[8] = {trace_kernel<false, 0>, trace_kernel<false, 1>, trace_kernel<false, 2>, trace_kernel<false, 3>,
-                                          trace_kernel<false, 4>, trace_kernel<false, 5>, trace_kernel<false, 6>, trace_kernel<false, 7>};
-        const Kernel kernel = g_counting ? trace_kernel<true, kGeomAll> : by_geom[s->geom_mask & kGeomAll];   // counting: one copy, all code
+        static const Kernel plain[8] = {trace_kernel<false, 0, false>, trace_kernel<false, 1, false>, trace_kernel<false, 2, false>, trace_kernel<false, 3, false>,
+                                        trace_kernel<false, 4, false>, trace_kernel<false, 5, false>, trace_kernel<false, 6, false>, trace_kernel<false, 7, false>};
+        static const Kernel rich[8] = {trace_kernel<false, 0, true>, trace_kernel<false, 1, true>, trace_kernel<false, 2, true>, trace_kernel<false, 3, true>,
+                                       trace_kernel<false, 4, true>, trace_kernel<false, 5, true>, trace_kernel<false, 6, true>, trace_kernel<false, 7, true>};
+        const Kernel kernel = g_counting ? trace_kernel<true, kGeomAll, true>                       // counting: one copy, all code
+                                         : (s->rich ? rich : plain)[s->geom_mask & kGeomAll];
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, stream, s->d, P);
         HIP_TRY(hipGetLastError());
     }
@@ -1200,8 +1208,14 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
         else if (t == QD_GEOM_CSG) s->geom_mask |= kGeomCsg;
         else if (t != QD_GEOM_MESH && t != QD_GEOM_PLANE) s->geom_mask |= kGeomPrim;
     }
+    s->rich = false;
+    for (uint32_t i = 0; i < desc->n_textures; ++i) {
+        const int t = desc->textures[i].type;
+        if (t != QD_TEX_CONST && t != QD_TEX_CHECKER && t != QD_TEX_FRESNEL) s->rich = true;
+    }
+    for (uint32_t i = 0; i < desc->n_nodes; ++i) if (desc->nodes[i].bump_tex >= 0) s->rich = true;
 #ifdef QD_NO_GEOM_MASK
-    s->geom_mask = kGeomAll;
+    s->geom_mask = kGeomAll; s->rich = true;
 #endif
     s->n_lanes = (uint32_t)(g_num_cu > 0 ? g_num_cu : 256) * kWavesPerCU * 64u;
     if (!rc && hipMalloc((void**)&s->stats, (24 + 6 * 4096) * sizeof(unsigned long long)) != hipSuccess) rc = set_err("hipMalloc(stats) failed");
