@@ -1,4 +1,5 @@
-"""Exploratory GPU-vs-oracle comparison over the fixture scenes (development aid, not a test)."""
+"""Exploratory GPU-vs-oracle comparison over the fixture scenes (development aid kept under tests/ because it uses the
+oracle; pytest does not collect it)."""
 import json
 import os
 import sys
@@ -6,7 +7,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 sys.path.insert(0, ROOT)
 import oracle  # noqa: E402
 from raytracing_amd import device, host  # noqa: E402
