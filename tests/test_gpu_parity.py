@@ -418,3 +418,32 @@ def test_aa_in_steps_equals_the_single_call(load_scene):
     finally:
         ds.close()
         _aa_settings(s, **old)
+
+
+@pytest.mark.parametrize("name", ["synthetic", "kdtree_fixed.qdmg", "lecture7_fixed.qdmg", "heightfield_fixed.qdmg", "bumpmap_fixed.qdmg"])
+def test_specialised_kernel_copy_equals_the_all_code_copy(load_scene, data_dir, name):
+    """launch() picks a kernel copy by what the scene holds (heightfield / CSG / other primitives / rich textures compiled
+    out when absent); the counting build always runs the copy with everything.  Same source, so same hits and colours."""
+    if name == "synthetic":
+        s = host.Scene.synthetic(64, seed=7, width=256, height=160, max_trace_depth=6, env_folder=os.path.join(data_dir, "env", "forest"))
+        old = None
+    else:
+        s = load_scene(name)
+        old = _aa_settings(s, want_aa=0)
+    W, H = s.settings.frame_width, s.settings.frame_height
+    rect = (W // 4, H // 4, W // 4 + min(256, W // 2), H // 4 + min(160, H // 2))
+    ds = device.DeviceScene(s)
+    try:
+        rgb0, (hn0, ht0, hd0), st0 = ds.render(*rect, hits=True)
+        device.set_counting(True)
+        try:
+            rgb1, (hn1, ht1, hd1), st1 = ds.render(*rect, hits=True)
+        finally:
+            device.set_counting(False)
+    finally:
+        ds.close()
+        if old is not None:
+            _aa_settings(s, **old)
+    assert np.array_equal(hn0, hn1) and np.array_equal(ht0, ht1) and np.array_equal(hd0.view(np.uint64), hd1.view(np.uint64))
+    assert np.abs(rgb0 - rgb1).max() <= SUM_ORDER_TOL
+    assert st0["rays"] == st1["rays"] and st0["shadow_rays"] == st1["shadow_rays"]
