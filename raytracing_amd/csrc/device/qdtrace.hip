@@ -1281,7 +1281,8 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
     int err_flag = 0;
     TRY2(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
     if (err_flag) { cleanup(); return set_err("qd_render: ray queue overflow on device"); }
-    TRY2(hipMemcpy2D(rgb, pitch * sizeof(float), d_rgb, (size_t)rw * 3 * sizeof(float), (size_t)rw * 3 * sizeof(float), rh, hipMemcpyDeviceToHost));
+    if (pitch == (size_t)rw * 3) TRY2(hipMemcpy(rgb, d_rgb, npx * 3 * sizeof(float), hipMemcpyDeviceToHost));      // contiguous rows: one copy
+    else TRY2(hipMemcpy2D(rgb, pitch * sizeof(float), d_rgb, (size_t)rw * 3 * sizeof(float), (size_t)rw * 3 * sizeof(float), rh, hipMemcpyDeviceToHost));
     if (hit_node) {
         TRY2(hipMemcpy(hit_node, d_hn, npx * sizeof(int32_t), hipMemcpyDeviceToHost));
         TRY2(hipMemcpy(hit_tri, d_ht, npx * sizeof(int32_t), hipMemcpyDeviceToHost));
