@@ -130,9 +130,7 @@ class FrameRenderer:
         self._coll_broadcast(frame)
         cur.synchronize()
         n = self.dscene.aa_begin(frame.data_ptr())          # identical on every rank: a function of the frame alone
-        per = (n + self.world - 1) // self.world
-        first = min(n, self.rank * per)
-        count = min(n, first + per) - first
+        per, first, count = sharding.aa_slice(n, self.rank, self.world)
         taps = torch.zeros((max(per, 1), 4, 3), dtype=torch.float32, device=self.dev)
         self.dscene.aa_trace_part(first, count, taps.data_ptr(), stream=cur.cuda_stream)
         all_taps = torch.zeros((self.world,) + tuple(taps.shape), dtype=torch.float32, device=self.dev) if self.rank == 0 else None

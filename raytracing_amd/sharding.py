@@ -42,3 +42,11 @@ def untile(gathered, width, height, tile, world):
             assert k < tpr
             img[y0:y1, x0:x1] = gathered[r, k, : y1 - y0, : x1 - x0]
     return img
+
+
+def aa_slice(n_listed, rank, world):
+    """Slice of the AA pass's pixel list that `rank` traces: (pixels per rank, first pixel, count).  Blocks of equal size
+    in rank order, the tail ranks possibly short or empty, so that the gathered taps are in list order."""
+    per = (n_listed + world - 1) // world
+    first = min(n_listed, rank * per)
+    return per, first, min(n_listed, first + per) - first

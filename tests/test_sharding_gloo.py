@@ -65,3 +65,17 @@ def test_tile_ownership_is_a_partition():
         assert (seen == 1).all()
         tx, ty = sharding.tile_grid(W, H, tile)
         assert total == tx * ty
+
+
+def test_aa_slices_cover_the_list_in_rank_order():
+    for n in (0, 1, 7, 8, 9, 1000, 12345):
+        for world in (1, 2, 3, 8):
+            nxt = 0
+            for r in range(world):
+                per, first, count = sharding.aa_slice(n, r, world)
+                assert first == min(n, r * per) and 0 <= count <= per
+                if count:
+                    assert first == nxt
+                    nxt = first + count
+            assert nxt == n
+            assert per * world >= n
