@@ -48,9 +48,10 @@ def build_scene(args):
     return scene, name
 
 
-def cpu_baseline(scene, budget_s=12.0):
+def cpu_baseline(scene, budget_s=12.0, gpu_frame=None):
     """The CPU oracle (a port of the reference's path) timed on one host core over a strided pixel
-    sample of the same frame; reported only, never the thing measured as `value`."""
+    sample of the same frame; reported only, never the thing measured as `value`.  The colours the oracle computes
+    for that sample are compared (untimed) with the frame the GPU rendered: second return value."""
     import numpy as np
     import oracle
     W, H = scene.settings.frame_width, scene.settings.frame_height
@@ -64,16 +65,22 @@ def cpu_baseline(scene, budget_s=12.0):
     t = time.perf_counter(); _, _, st = oracle.render_pixels(scene, xy, rng_mode=1, threads=1); dt = time.perf_counter() - t
     n = int(min(W * H, max(4096, 4096 * budget_s / max(dt, 1e-3))))
     xy = sample(n)
-    t = time.perf_counter(); _, _, st = oracle.render_pixels(scene, xy, rng_mode=1, threads=1); dt = time.perf_counter() - t
+    t = time.perf_counter(); orgb, _, st = oracle.render_pixels(scene, xy, rng_mode=1, threads=1); dt = time.perf_counter() - t
     out = {"value": st["rays"] / dt, "unit": "rays/s", "cores": 1, "kind": "port",
            "sample": f"{len(xy)} pixels on a uniform stride over the same frame ({st['rays']} rays, {dt:.1f} s, 1 thread)"}
+    parity = None
+    if gpu_frame is not None:
+        err = np.abs(gpu_frame[xy[:, 1], xy[:, 0]].astype(np.float64) - orgb.astype(np.float64)).max(axis=1)
+        parity = {"checked_px": int(len(xy)), "max_err": float(np.nanmax(err)), "bad_px": int((~(err <= 1e-4)).sum()), "tol": 1e-4,
+                  "note": "GPU frame vs the oracle's colours of the cpu_baseline sample (untimed); bad_px = pixels off by more than tol, "
+                          "budget 0.01 % (near-tie rays)"}
     # also one thread per core of this rank's CPU share (the reference itself has one render thread)
     nthr = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1))
     if nthr > 1:
         xy = sample(int(min(W * H, len(xy) * min(nthr, 8))))
         t = time.perf_counter(); _, _, st = oracle.render_pixels(scene, xy, rng_mode=1, threads=nthr); dt = time.perf_counter() - t
         out["all_cores"] = {"value": st["rays"] / dt, "cores": nthr, "sample": f"{len(xy)} pixels, {st['rays']} rays, {dt:.1f} s"}
-    return out
+    return out, parity
 
 
 def main():
@@ -203,7 +210,10 @@ def main():
                          "kd_nodes_visited": cstats["kd_nodes_visited"], "tris_tested": cstats["tris_tested"]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene)
+            fr.render_shard()
+            gpu_frame = fr.gather().cpu().numpy()
+            fr.check()
+            out["cpu_baseline"], out["parity"] = cpu_baseline(scene, gpu_frame=gpu_frame)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -54,6 +54,10 @@ int qdh_save_bmp(const char* path, const float* rgb, int width, int height, size
 float* qdh_load_image(const char* path, uint32_t* width, uint32_t* height);
 void   qdh_free(void* p);
 
+/* Test hook: the front end's matrix / Transform arithmetic (src/matrix.cpp:10-133, src/transform.cpp:5-73) on one
+ * 16-double record, 52 doubles out; checked bit for bit against the reference's own object code (tests/golden/ref/). */
+void qdh_math_probe(const double in[16], double out[52]);
+
 void qdh_free_scene(qdh_scene* s);
 const char* qdh_last_error(void);
 

@@ -45,8 +45,27 @@ def lib():
         L.orc_convert_to_8bit.argtypes = [C.c_double]
         L.orc_to_rgb32.restype = None
         L.orc_to_rgb32.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_camera_rays.restype = C.c_int
+        L.orc_camera_rays.argtypes = [P(abi.QdSceneDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_trace_rays.restype = C.c_int
+        L.orc_trace_rays.argtypes = [P(abi.QdSceneDesc), C.c_size_t, C.c_void_p, C.c_void_p]
+        L.orc_unit_funcs.restype = C.c_int
+        L.orc_unit_funcs.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
+
+
+REF_RECORD = np.dtype([("node", "<i4"), ("pad", "<i4"), ("dist", "<f8"), ("ip", "<f8", 3), ("normal", "<f8", 3),
+                       ("u", "<f8"), ("v", "<f8"), ("rgb", "<f4", 3), ("padf", "<f4")])
+
+
+def trace_rays(scene, rays):
+    """Raytrace's node loop + bump + Shade for explicit rays (n x 6 f64): records in oracle/ref_driver.cpp's layout."""
+    rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 6)
+    out = np.zeros(len(rays), REF_RECORD)
+    if lib().orc_trace_rays(scene.desc_ptr, len(rays), rays.ctypes.data, out.ctypes.data) != 0:
+        raise RuntimeError("orc_trace_rays failed")
+    return out
 
 
 def render_rect(scene, x0, y0, x1, y1, camera=None, settings=None, hits=False, rng_mode=1, threads=None):

@@ -9,11 +9,20 @@
  * cites the reference file:line it follows.  Input is the same flat qd_scene_desc the device
  * library consumes (include/qdtrace.h), so oracle and HIP path see identical scene bytes.
  *
- * Parity pin: the reference itself cannot be built in this image without stand-in SDL/OpenEXR
- * headers (src/mesh.cpp:5, src/main.cpp:2, src/bitmap.cpp:9-11), so the oracle is pinned against
- * the outputs of the unmodified reference recorded in SURVEY.md sections 4/6/8(c): KD statistics,
- * per-ray box/triangle test averages, ray counts, spot pixels and whole-frame md5 digests of the
- * raw float framebuffer (tests/golden/reference_kats.json, tests/test_oracle_kats.py).
+ * Parity pin, two layers:
+ *  (1) by the reference's own object code: sixteen of its translation units (everything but main, mesh, heightfield,
+ *      random_generator, bitmap, sdl, which include SDL / OpenEXR headers the image lacks) are compiled unmodified by
+ *      oracle/ref_build.sh and driven by oracle/ref_driver.cpp; their outputs for a frame of camera rays, random rays and
+ *      function-level inputs are committed under tests/golden/ref/ and this file must reproduce them BIT FOR BIT
+ *      (tests/test_ref_vectors.py): Node::Intersect + Transform, Plane / Sphere / Cube / RegularPolygon / CsgOp,
+ *      BBox, Reflect / Refract / Faceforward / FresnelRatio / OrthonormalSystem, Const / Lambert / Phong / BlinnPhong /
+ *      OrenNayar / Layered, shadow rays, Checker / Mandelbrot / Procedural / ConstantColor / Fresnel / Bumps.
+ *  (2) mesh, KD-tree, heightfield, bitmap, cubemap, reflection / refraction (the units that cannot be built here without
+ *      stand-in headers): pinned against outputs of the unmodified reference recorded in SURVEY.md sections 4/6/8(c)
+ *      -- KD statistics, per-ray box/triangle test averages, ray counts, spot pixels and whole-frame md5 digests of the
+ *      raw float framebuffer (tests/golden/reference_kats.json, tests/test_oracle_kats.py).  No committed recipe
+ *      reproduces those numbers (the survey's build used stand-in SDL / OpenEXR headers), so for these rows parity is
+ *      "pinned by recorded reference outputs only".
  */
 #include <algorithm>
 #include <atomic>
@@ -984,4 +993,76 @@ extern "C" void orc_to_rgb32(const float* rgb, size_t n_pixels, int srgb, int rs
         }
         out[i] = (c[2] << bs) | (c[1] << gs) | (c[0] << rs);
     }
+}
+
+// ------------------------------------------------------------------ entry points for the reference-pinned vectors
+// (tests/golden/ref/, produced by oracle/ref_driver.cpp from the reference's own object code)
+
+// Camera::GetScreenRay for every pixel of a rectangle: 6 f64 per pixel {start, dir}.
+extern "C" int orc_camera_rays(const qd_scene_desc* S, int x0, int y0, int x1, int y1, double* out) {
+    if (!S || !out) return -1;
+    const Ctx c = make_ctx(S, nullptr, nullptr, 1);
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            const Ray r = screen_ray(c, x, y);
+            *out++ = r.start.x; *out++ = r.start.y; *out++ = r.start.z; *out++ = r.dir.x; *out++ = r.dir.y; *out++ = r.dir.z;
+        }
+    return 0;
+}
+
+// Raytrace's node loop + bump + Shade (src/main.cpp:23-49) for explicit rays at depth 0; one 96-byte record per ray in
+// ref_driver.cpp's layout: i32 node, i32 0, f64 distance, ip[3], normal[3] (before the bump), u, v, f32 rgb[3], f32 0.
+extern "C" int orc_trace_rays(const qd_scene_desc* S, size_t n, const double* rays, void* out_records) {
+    if (!S || !rays || !out_records) return -1;
+    Ctx c = make_ctx(S, nullptr, nullptr, 1);
+    struct Rec { int node, pad; double dist, ip[3], nrm[3], u, v; float rgb[3], padf; };
+    static_assert(sizeof(Rec) == 96, "record layout");
+    Rec* out = (Rec*)out_records;
+    for (size_t i = 0; i < n; ++i) {
+        Ray ray; ray.start = ld3(rays + i * 6); ray.dir = ld3(rays + i * 6 + 3); ray.depth = 0; ray.path = (uint32_t)i;
+        Rec r; memset(&r, 0, sizeof r);
+        Info info;
+        r.node = closest_node(c, ray.start, ray.dir, info);
+        if (r.node >= 0) {
+            r.dist = info.distance;
+            r.ip[0] = info.ip.x; r.ip[1] = info.ip.y; r.ip[2] = info.ip.z;
+            r.nrm[0] = info.normal.x; r.nrm[1] = info.normal.y; r.nrm[2] = info.normal.z;
+            r.u = info.u; r.v = info.v;
+        }
+        const Col col = raytrace(c, ray);
+        r.rgb[0] = col.r; r.rgb[1] = col.g; r.rgb[2] = col.b;
+        out[i] = r;
+    }
+    return 0;
+}
+
+// Function-level vectors, words [0..22] of ref_driver.cpp's 80-f64 record (BBox and vector helpers); input 16 f64 per
+// record {a, b, c, d, s, 0, 0, 0}.  Words without a counterpart here (Split, GetArea: host builder) are written as NaN.
+extern "C" int orc_unit_funcs(size_t n, const double* in, double* out) {
+    if (!in || !out) return -1;
+    const double nan = std::nan("");
+    for (size_t i = 0; i < n; ++i) {
+        const double* r = in + i * 16;
+        double* o = out + i * 23;
+        const V a = ld3(r), b = ld3(r + 3), c = ld3(r + 6), d = ld3(r + 9);
+        const double s = r[12];
+        Box box;
+        box.mn = mk(std::min(a.x, b.x), std::min(a.y, b.y), std::min(a.z, b.z));   // BBox::MakeEmpty + Add, src/bbox.cpp:8-22
+        box.mx = mk(std::max(a.x, b.x), std::max(a.y, b.y), std::max(a.z, b.z));
+        const V dir = normalize(d);
+        o[0] = box_inside(box, c) ? 1. : 0.;
+        o[1] = box_test(box, c, dir) ? 1. : 0.;
+        o[2] = box_closest(box, c, dir);
+        o[3] = o[4] = o[5] = nan;
+        const V nrm = normalize(a - b), dn = dir;
+        auto put = [&](int at, const V& v) { o[at] = v.x; o[at + 1] = v.y; o[at + 2] = v.z; };
+        put(6, reflect(d, nrm));
+        put(9, refract(dn, nrm, s));
+        put(12, faceforward(dn, nrm));
+        o[15] = fresnel_ratio(dn, nrm, s);
+        V r1, r2; orthonormal_system(nrm, r1, r2);
+        put(16, r1); put(19, r2);
+        o[22] = 0.;
+    }
+    return 0;
 }

@@ -37,6 +37,12 @@ int orc_render_frame(const qd_scene_desc* S, float* rgb, int rng_mode, orc_stats
 
 unsigned orc_convert_to_8bit(double x);
 
+/* Reference-pinned vectors (tests/golden/ref/, oracle/ref_driver.cpp): camera rays of a rectangle (6 f64 per pixel),
+ * Raytrace's node loop + bump + Shade for explicit rays (96-byte records), function-level BBox / vector helpers. */
+int orc_camera_rays(const qd_scene_desc* S, int x0, int y0, int x1, int y1, double* out);
+int orc_trace_rays(const qd_scene_desc* S, size_t n, const double* rays, void* out_records);
+int orc_unit_funcs(size_t n, const double* in, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,39 @@ extern "C" float* qdh_load_image(const char* path, uint32_t* w, uint32_t* h) {
     return out;
 }
 
+// Test hook: the host front end's matrix / transform arithmetic on one 16-f64 record {a, b, c, d, s, 0, 0, 0}, laid out as
+// words [23..74] of oracle/ref_driver.cpp's function-level record (what the reference's src/matrix.cpp and
+// src/transform.cpp compute for the same input): Determinant, Inverse, Transpose of the matrix with rows a, b, c;
+// RotationAroundX(s) * RotationAroundY(a.x) * RotationAroundZ(a.y); d * M; a ^ b; a * b; |a|; two zeros; then
+// Transform{Scale(a), Rotate(b * 90), Translate(c)}: Point(d), UndoPoint(d), Direction(d), UndoDirection(d), Normal(d).
+extern "C" void qdh_math_probe(const double in[16], double out[52]) {
+    const V3 a(in[0], in[1], in[2]), b(in[3], in[4], in[5]), c(in[6], in[7], in[8]), d(in[9], in[10], in[11]);
+    const double s = in[12];
+    int k = 0;
+    auto putv = [&](const V3& v) { out[k++] = v.x; out[k++] = v.y; out[k++] = v.z; };
+    auto putm = [&](const M3& m) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out[k++] = m.m[i][j]; };
+    M3 m(0.);
+    for (int j = 0; j < 3; ++j) { m.m[0][j] = a[j]; m.m[1][j] = b[j]; m.m[2][j] = c[j]; }
+    out[k++] = determinant(m);
+    putm(inverse(m));
+    putm(transpose(m));
+    putm(rot_x(s) * rot_y(in[0]) * rot_z(in[1]));
+    putv(d * m);
+    putv(cross(a, b));
+    out[k++] = dot(a, b);
+    out[k++] = length(a);
+    out[k++] = 0.; out[k++] = 0.;
+    Transform t;
+    t.scale(a.x, a.y, a.z);
+    t.rotate(b.x * 90, b.y * 90, b.z * 90);
+    t.translate(c);
+    putv(d * t.m + t.offset);            // Transform::Point, src/transform.cpp:44-47
+    putv((d - t.offset) * t.inv);        // UndoPoint :49-52
+    putv(d * t.m);                       // Direction :54-57
+    putv(d * t.inv);                     // UndoDirection :59-62
+    putv(d * t.invT);                    // Normal :64-67
+}
+
 // ---------------------------------------------------------------------------
 // Synthetic benchmark scene: a displaced n x n grid (2*n*n triangles) of "glass"
 // over a checker floor.  Everything is derived from raw mt19937(seed) words so the

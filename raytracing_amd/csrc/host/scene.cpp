@@ -107,20 +107,6 @@ void get3doubles(int line, std::string s, double& a, double& b, double& c) {
     if (3 != sscanf(s.c_str(), "%lf%lf%lf", &a, &b, &c)) fail("line %d: Expected three double values", line);
 }
 
-struct Transform {   // src/transform.cpp:5-42
-    M3 m{1.}, inv{1.}, invT{1.};
-    V3 offset;
-    void scale(double x, double y, double z) {
-        M3 s(x); s.m[1][1] = y; s.m[2][2] = z;
-        m = m * s; inv = inverse(m); invT = transpose(inv);
-    }
-    void rotate(double yaw, double pitch, double roll) {
-        m = m * rot_x(to_radians(pitch)) * rot_y(to_radians(yaw)) * rot_z(to_radians(roll));
-        inv = inverse(m); invT = transpose(inv);
-    }
-    void translate(const V3& v) { offset = v; }   // overwrites, does not accumulate
-};
-
 Kind kind_of_class(const std::string& c, bool& known) {
     known = true;
     if (c == "GlobalSettings") return Kind::Settings;

@@ -106,4 +106,18 @@ inline M3 rot_z(double ang) {
 constexpr double kPi = 3.141592653589793238;          // src/constants.h:10
 inline double to_radians(double deg) { return deg / 180. * kPi; }  // src/utils.h:19
 
+struct Transform {   // src/transform.cpp:5-42
+    M3 m{1.}, inv{1.}, invT{1.};
+    V3 offset;
+    void scale(double x, double y, double z) {
+        M3 s(x); s.m[1][1] = y; s.m[2][2] = z;
+        m = m * s; inv = inverse(m); invT = transpose(inv);
+    }
+    void rotate(double yaw, double pitch, double roll) {
+        m = m * rot_x(to_radians(pitch)) * rot_y(to_radians(yaw)) * rot_z(to_radians(roll));
+        inv = inverse(m); invT = transpose(inv);
+    }
+    void translate(const V3& v) { offset = v; }   // overwrites, does not accumulate
+};
+
 }  // namespace qdh

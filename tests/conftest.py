@@ -31,3 +31,19 @@ def load_scene():
         return cache[name]
 
     return _load
+
+
+def synthetic_vertex_sha256(scene):
+    """SHA-256 of the flattened vertex buffer (tri_verts, 9 f64 per triangle) of a scene."""
+    import hashlib
+
+    import numpy as np
+    d = scene.desc
+    buf = np.ctypeslib.as_array(d.tri_verts, shape=(int(d.n_tris) * 9,))
+    return hashlib.sha256(memoryview(buf)).hexdigest()
+
+
+@pytest.fixture(scope="session")
+def synthetic_sha():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "synthetic_sha256.json")))

@@ -73,6 +73,53 @@ def test_synthetic_mesh_scene_matches_oracle(data_dir):
     assert r["gpu"]["rays"] > 2 * r["n"]      # glass: secondary + shadow rays are really traced
 
 
+def test_full_size_bench_scene_matches_oracle(data_dir, synthetic_sha):
+    """BASELINE configs[4] at FULL size (10 035 200 triangles, 3840x2160, maxTraceDepth 8, forest cubemap): the very scene
+    bench.py times.  The whole frame is rendered on the device with primary hits; a strided 1/64 pixel subset
+    (SURVEY.md 8(d) input 5) is compared with the oracle -- hit node / triangle / bits of the distance inside the 0.01 %
+    near-tie budget, colour <= 1e-4 -- and the ray population (radiance, shadow, depth-killed) on four rectangles.
+    Exercises what the miniature cannot: 28-bit record indices, > 4 GB leaf_verts offsets, a 46 M node tree, deep stacks."""
+    from conftest import synthetic_vertex_sha256
+    s = host.Scene.synthetic(2240, seed=42, width=3840, height=2160, max_trace_depth=8,
+                             env_folder=os.path.join(data_dir, "env", "forest"))
+    assert s.desc.n_tris == 10035200
+    assert synthetic_vertex_sha256(s) == synthetic_sha["n2240"]["sha256"]
+    W, H = 3840, 2160
+    ds = device.DeviceScene(s)
+    try:
+        info = ds.kd_info()
+        assert info["nodes"] > 30_000_000 and info["leaf_refs"] * 72 > 2**31      # really the big tree
+        rgb, (hn, ht, hd), st = ds.render(hits=True)
+        assert st["primary_rays"] == W * H and st["rays"] > 2 * W * H
+        ys, xs = np.meshgrid(np.arange(5, H, 8), np.arange(3, W, 8), indexing="ij")
+        xy = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
+        assert len(xy) == W * H // 64
+        orgb, (ohn, oht, ohd), ost = oracle.render_pixels(s, xy, hits=True, rng_mode=1, threads=16)
+        g = lambda a: a[xy[:, 1], xy[:, 0]]
+        budget = max(1, int(len(xy) * NEAR_TIE_BUDGET))
+        id_mismatch = int(((g(hn) != ohn) | (g(ht) != oht)).sum())
+        dist_mismatch = int((g(hd).view(np.uint64) != ohd.view(np.uint64)).sum())
+        err = np.abs(g(rgb).astype(np.float64) - orgb.astype(np.float64)).max(axis=1)
+        bad = int((~(err <= COLOUR_TOL)).sum())
+        print(f"full-size subset: {len(xy)} px, id mismatches {id_mismatch}, distance mismatches {dist_mismatch}, "
+              f"bad colours {bad}, max err {float(np.nanmax(err)):.3e}, mesh-hit pixels {int((g(ht) >= 0).sum())}")
+        assert int((g(ht) >= 0).sum()) > len(xy) // 4            # the mesh fills a good part of the frame
+        assert id_mismatch <= budget and dist_mismatch <= budget, (id_mismatch, dist_mismatch)
+        assert bad <= budget, (bad, float(np.nanmax(err)))
+        # ray population on rectangles spread over sky, mesh horizon, mesh interior and floor
+        for (x0, y0) in [(64, 32), (1800, 700), (3500, 1100), (900, 1900)]:
+            x1, y1 = x0 + 256, y0 + 64
+            part, _, pst = ds.render(x0, y0, x1, y1)
+            opart, _, opst = oracle.render_rect(s, x0, y0, x1, y1, rng_mode=1, threads=16)
+            assert np.abs(part - rgb[y0:y1, x0:x1]).max() <= SUM_ORDER_TOL
+            assert int((~(np.abs(part.astype(np.float64) - opart).max(axis=2) <= COLOUR_TOL)).sum()) <= 2
+            assert abs(pst["rays"] - opst["rays"]) <= 8 and abs(pst["shadow_rays"] - opst["shadow_queries"]) <= 8, (pst, opst)
+            assert abs(pst["depth_killed"] - opst["depth_killed"]) <= 8
+    finally:
+        ds.close()
+        s.close()
+
+
 def test_ragged_rectangles_and_pitch(load_scene):
     s = load_scene("window_fixed.qdmg")
     s.settings.want_aa = 0
@@ -121,7 +168,7 @@ def test_tile_sharded_frame_equals_single_rectangle(load_scene):
 
 def test_4k_heightfield_properties(load_scene):
     """BASELINE config 4 at 3840x2160: too big for a full oracle frame in seconds, so check
-    size-independent properties: a strided pixel sample against the oracle, run-to-run determinism."""
+    size-independent properties: a strided pixel sample against the oracle, run-to-run agreement."""
     s = load_scene("heightfield_fixed.qdmg")
     st = s.settings
     old = (st.frame_width, st.frame_height, st.want_aa)
@@ -130,7 +177,8 @@ def test_4k_heightfield_properties(load_scene):
     try:
         a, _, sa = ds.render()
         b, _, sb = ds.render()
-        assert np.array_equal(a, b) and sa["rays"] == sb["rays"]
+        # colours are summed with float atomics in arrival order: two renders agree to rounding, not to the bit
+        assert np.abs(a - b).max() <= SUM_ORDER_TOL and sa["rays"] == sb["rays"]
         ys, xs = np.meshgrid(np.arange(3, 2160, 29), np.arange(5, 3840, 31), indexing="ij")
         xy = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
         orgb, _, _ = oracle.render_pixels(s, xy, rng_mode=1, threads=16)

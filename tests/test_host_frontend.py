@@ -196,3 +196,17 @@ def test_synthetic_scene_is_reproducible():
     vc = np.ctypeslib.as_array(c.desc.tri_verts, shape=(c.desc.n_tris * 9,))
     assert a.desc.n_tris == 2 * 16 * 16 and np.array_equal(va, vb) and not np.array_equal(va, vc)
     assert a.desc.meshes[0].kd_root >= 0 and a.settings.max_trace_depth == 3
+
+
+@pytest.mark.parametrize("n", [96, 2240])
+def test_synthetic_scene_vertex_buffer_is_the_committed_one(data_dir, synthetic_sha, n):
+    """SURVEY.md 8(d) input 5: the generator is reproducible from (n, seed) alone; the SHA-256 of the vertex buffer
+    of the bench scene (n = 2240, 10 035 200 triangles) and of the miniature the parity tests use is committed."""
+    from conftest import synthetic_vertex_sha256
+    s = host.Scene.synthetic(n, seed=42, width=3840, height=2160, max_trace_depth=8,
+                             env_folder=os.path.join(data_dir, "env", "forest"))
+    try:
+        assert s.desc.n_tris == synthetic_sha[f"n{n}"]["triangles"] == 2 * n * n
+        assert synthetic_vertex_sha256(s) == synthetic_sha[f"n{n}"]["sha256"]
+    finally:
+        s.close()
