@@ -294,6 +294,21 @@ int qd_render_tiles_async(qd_scene* scene, const qd_camera* camera, const qd_set
                           int tile, int tile_phase, int tile_stride,
                           float* rgb_dev, qd_stats* stats_dev, void* hip_stream);
 
+/* No counterpart in the reference.  For callers that cannot allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  Same arguments, pixel selection and output layout as qd_render_tiles_async,
+ * but the call allocates nothing (no hipMalloc / hipFree, no events): the ray queues and control words live in a
+ * file-scope __device__ array of 96 MiB inside libqdtrace.so (each GPU the library runs on holds its copy until the
+ * process ends; qd_init looks its address up once per device).  The frame is one launch of the trace kernel on as many
+ * lanes as 96 MiB hold at 88 B x (queue depth of this scene at settings->max_trace_depth) per lane.
+ * Limits: fails with a clear error when that is less than one wave per CU (queue depth > ~69 on 256 CUs), never
+ * falls back to allocating.  Every call on one GPU shares that GPU's array, which keeps the last call's contents (the
+ * call clears the control words it needs zeroed): calls that OVERLAP on one GPU -- different streams, or another
+ * process thread -- race; calls on one stream run in order and are safe.  Outputs equal qd_render_tiles_async's up to
+ * the order of float additions (<= 2e-6). */
+int qd_render_tiles_noalloc_async(qd_scene* scene, const qd_camera* camera, const qd_settings* settings,
+                                  int tile, int tile_phase, int tile_stride,
+                                  float* rgb_dev, qd_stats* stats_dev, void* hip_stream);
+
 /* Replaces: nothing in the reference (it renders one frame at a time on one thread, src/main.cpp:163-168).
  * Binds a working set of the scene to `hip_stream` and sizes it for max_trace_depth now, so that later
  * qd_render_tiles_async calls on that stream allocate nothing (see "Frames in flight" above). */

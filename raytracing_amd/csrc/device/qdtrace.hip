@@ -849,8 +849,19 @@ __global__ void aa_resolve_kernel(const float* __restrict__ first, const float* 
     next[i] = r; next[i + 1] = g; next[i + 2] = b;
 }
 
+// ------------------------------------------------------------------------------------------ static scratch
+// Working memory of qd_render_tiles_noalloc_async: control words + per-lane ray queues in a file-scope device array, so
+// that the call allocates nothing.  One copy per GPU, held until the process ends; every call on a GPU shares it.
+// In host code the array's NAME is only a stand-in: its device address is looked up once per device in qd_init
+// (hipGetSymbolAddress) and kept in g_scratch_ptr[device]; host code uses that pointer, never the name.
+constexpr size_t kScratchBytes = (size_t)96 << 20;        // 96 MiB
+constexpr size_t kScratchCtlBytes = 4096;                 // control words of one pass (kPassWords * 4 = 2304 B), then the queues
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+constexpr int kMaxDevices = 64;
+
 // ------------------------------------------------------------------------------------------ host side
 thread_local std::string g_err;
+unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};     // device address of `scratch` on each device qd_init has bound
 int g_device = -1;
 int g_num_cu = 0;
 bool g_counting = false;
@@ -1031,6 +1042,12 @@ extern "C" int qd_init(int device) {
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (device < kMaxDevices && !g_scratch_ptr[device]) {    // this device's copy of the static scratch array (device is current)
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return set_err(std::string("qd_init: hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        g_scratch_ptr[device] = (unsigned char*)p;
+    }
     g_device = device;
     g_num_cu = prop.multiProcessorCount;
     return 0;
@@ -1524,6 +1541,59 @@ extern "C" int qd_render_tiles_async(qd_scene* s, const qd_camera* cam, const qd
     if (stats_dev) HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(qd_stats), stream));
     if (P.n_units == 0) return 0;
     return launch(s, P, st->max_trace_depth, stream);
+}
+
+// The tile-sharded render without a single allocation: queues and control words live in the static `scratch` array
+// (through this device's g_scratch_ptr), the frame is ONE launch of the trace kernel (no hand-over lists, so waves keep
+// their ray trees to the end) on as many lanes as the scratch holds for this scene's queue depth.
+extern "C" int qd_render_tiles_noalloc_async(qd_scene* s, const qd_camera* cam, const qd_settings* st, int tile, int tile_phase,
+                                             int tile_stride, float* rgb_dev, qd_stats* stats_dev, void* hip_stream) {
+    if (!s || !cam || !st || !rgb_dev) return set_err("qd_render_tiles_noalloc_async: null argument");
+    if (tile < 8 || tile % 8 || tile_stride < 1 || tile_phase < 0 || tile_phase >= tile_stride) return set_err("qd_render_tiles_noalloc_async: bad tiling");
+    if (g_device < 0 || g_device >= kMaxDevices || !g_scratch_ptr[g_device]) return set_err("qd_render_tiles_noalloc_async: qd_init has not bound this device's scratch");
+    unsigned char* const ptr = g_scratch_ptr[g_device];
+    hipStream_t stream = (hipStream_t)hip_stream;
+    // queue depth this scene needs at this trace depth (same bound as acquire_set) -> lanes the scratch can hold
+    const uint64_t cap64 = (uint64_t)s->spawn0 + (uint64_t)s->spawn1 * st->max_trace_depth + 2;
+    const size_t lane_bytes = (size_t)cap64 * kEntryWords * 8;
+    const size_t max_lanes = (kScratchBytes - kScratchCtlBytes) / lane_bytes;
+    uint32_t waves = (uint32_t)std::min<size_t>(max_lanes / 64, s->n_lanes / 64);
+    waves &= ~7u;                                           // whole groups of eight: one wave per XCD label and queue
+    const uint32_t min_waves = (uint32_t)(g_num_cu > 0 ? g_num_cu : 256);
+    if (cap64 > 4096 || waves < min_waves)
+        return set_err("qd_render_tiles_noalloc_async: the ray queues of this scene at this maxTraceDepth (" + std::to_string(cap64) +
+                       " entries of 88 B per lane, one wave per CU at least) exceed the 96 MiB static scratch; use qd_render_tiles_async");
+    Params P; fill_common(P, cam, st);
+    P.mode = 1; P.tile = tile; P.phase = tile_phase; P.stride = tile_stride;
+    P.tiles_x = (st->frame_width + tile - 1) / tile;
+    const int tiles_y = (st->frame_height + tile - 1) / tile;
+    const int n_tiles = P.tiles_x * tiles_y;
+    const int n_owned = n_tiles > tile_phase ? (n_tiles - tile_phase + tile_stride - 1) / tile_stride : 0;
+    P.n_units = (uint32_t)n_owned * (uint32_t)((tile / kUnitSide) * (tile / kUnitSide));
+    P.rgb = rgb_dev; P.rgb_floats = (size_t)n_owned * tile * tile * 3;
+    P.stats = (unsigned long long*)stats_dev;
+    if (stats_dev) HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(qd_stats), stream));
+    if (P.n_units == 0) return 0;
+    uint32_t* ctl = (uint32_t*)ptr;
+    P.stack = (uint64_t*)(ptr + kScratchCtlBytes); P.stack_cap = (uint32_t)cap64; P.n_lanes = waves * 64u;
+    P.error_flag = s->error_flag;
+    P.queue_ctr = ctl; P.out_count = ctl + 8 * kCtlStride; P.pass_done = ctl + 16 * kCtlStride;
+    P.source = 0; P.grace = 0xffffffffu;                    // one pass that runs to the end: no task lists
+    P.in_count = nullptr; P.in_list = nullptr; P.out_list = nullptr; P.list_cap = 0;
+    // the scratch keeps the last call's contents: the control words must start at zero, the queues need not (every lane
+    // starts with an empty queue and only reads what it pushed)
+    HIP_TRY(hipMemsetAsync(ptr, 0, kScratchCtlBytes, stream));
+    HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));
+    using Kernel = void (*)(const DScene, const Params);
+    static const Kernel plain[8] = {trace_kernel<false, 0, false>, trace_kernel<false, 1, false>, trace_kernel<false, 2, false>, trace_kernel<false, 3, false>,
+                                    trace_kernel<false, 4, false>, trace_kernel<false, 5, false>, trace_kernel<false, 6, false>, trace_kernel<false, 7, false>};
+    static const Kernel rich[8] = {trace_kernel<false, 0, true>, trace_kernel<false, 1, true>, trace_kernel<false, 2, true>, trace_kernel<false, 3, true>,
+                                   trace_kernel<false, 4, true>, trace_kernel<false, 5, true>, trace_kernel<false, 6, true>, trace_kernel<false, 7, true>};
+    const Kernel kernel = g_counting ? trace_kernel<true, kGeomAll, true> : (s->rich ? rich : plain)[s->geom_mask & kGeomAll];
+    const uint32_t grid = P.n_units < waves ? P.n_units : waves;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, stream, s->d, P);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 extern "C" int qd_scene_bind_stream(qd_scene* s, int max_trace_depth, void* hip_stream) {

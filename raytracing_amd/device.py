@@ -38,6 +38,7 @@ def lib():
         L.qd_aa_end_device.argtypes = [C.c_void_p, P(abi.QdSettings), C.c_void_p, C.c_void_p]
         L.qd_render_tiles_async.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p]
+        L.qd_render_tiles_noalloc_async.argtypes = L.qd_render_tiles_async.argtypes
         L.qd_scene_bind_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.qd_untile_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.qd_quantize_bgr8_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
@@ -166,6 +167,15 @@ class DeviceScene:
         _check(lib().qd_render_tiles_async(self._h, C.byref(cam), C.byref(st), tile, phase, stride,
                                            C.c_void_p(rgb_dev_ptr), C.c_void_p(stats_dev_ptr or 0),
                                            C.c_void_p(stream or 0)), "qd_render_tiles_async")
+
+    def render_tiles_noalloc_async(self, rgb_dev_ptr, tile, phase, stride, stats_dev_ptr=None, stream=None,
+                                   camera=None, settings=None):
+        """qd_render_tiles_async for callers that cannot allocate: working memory is the library's static device array."""
+        st = settings if settings is not None else self.host_scene.settings
+        cam = camera if camera is not None else self.host_scene.camera
+        _check(lib().qd_render_tiles_noalloc_async(self._h, C.byref(cam), C.byref(st), tile, phase, stride,
+                                                   C.c_void_p(rgb_dev_ptr), C.c_void_p(stats_dev_ptr or 0),
+                                                   C.c_void_p(stream or 0)), "qd_render_tiles_noalloc_async")
 
     def bind_stream(self, stream, max_trace_depth=None):
         """Reserve a working set of the scene for launches on `stream` (frames in flight: one stream per frame)."""
