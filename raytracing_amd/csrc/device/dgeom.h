@@ -576,8 +576,8 @@ QD_DEV bool prim_intersect(const qd_geom& g, const DV& start, const DV& dir, GHi
 
 QD_DEV bool csg_op(int op, bool a, bool b) { return op == QD_CSG_AND ? (a && b) : (op == QD_CSG_PLUS ? (a || b) : (a && !b)); }
 
-// CsgOp::Intersect, src/geometry.cpp:184-234.  On the device the operands must be analytic primitives
-// (qd_scene_create rejects CSG over CSG / meshes / heightfields; the oracle handles those).
+// CsgOp::Intersect, src/geometry.cpp:184-234, for operands that are analytic primitives (the common case: this walk is
+// inlined into the node loop).  CSG over CSG / meshes / heightfields: csg_generic below.
 QD_DEV bool csg_intersect(const DScene& S, const qd_geom& g, const DV& start, const DV& dir, GHit& out) {
     const qd_geom ga = S.geoms[g.a], gb = S.geoms[g.b];
     GHit li, ri;
@@ -597,6 +597,85 @@ QD_DEV bool csg_intersect(const DScene& S, const qd_geom& g, const DV& start, co
             if (csg_op(g.c, inA, inB) != cur) { out = ri; return true; }
             const double prev = ri.dist;
             rhit = prim_intersect(gb, ri.ip + dir * 1e-6, dir, ri);
+            if (rhit) ri.dist += prev + 1e-6;
+        }
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------- CSG over any geometry
+// CsgOp::Intersect takes any Geometry* as operand (src/geometry.cpp:184-242): a mesh, a heightfield, another CsgOp.
+// Scenes that hold such a node run the kernel copy with kGeomCsgDeep; its walk is the same boundary walk as
+// csg_intersect above, with operands resolved by these functions.  Device code has no recursion: nesting is unrolled by
+// a template depth (kMaxCsgNesting levels of CSG nodes, qd_scene_create refuses deeper trees), each level a real
+// function so that the node loop of trace_nodes holds one call site, not the walk.
+constexpr int kMaxCsgNesting = 4;
+
+// Mesh::IsInside and Heightfield::IsInside are constant false (src/mesh.cpp:94-97, src/heightfield.h:14)
+template <int D> QD_DEV bool geom_inside_t(const DScene& S, int gi, const DV& p) {
+    const qd_geom g = S.geoms[gi];
+    if (g.type == QD_GEOM_CSG) {
+        if constexpr (D > 0) return csg_op(g.c, geom_inside_t<D - 1>(S, g.a, p), geom_inside_t<D - 1>(S, g.b, p));
+        else return false;
+    }
+    return leaf_inside(g, p);
+}
+
+// Closest hit of one non-CSG geometry of any kind, as a full record.  A mesh hit carries triangle + barycentrics (its
+// normal / uv are derived once for the winner by mesh_finish in assemble_info).
+template <bool STATS>
+__device__ __attribute__((noinline)) bool leaf_any_intersect(const DScene& S, int gi, const DV& start, const DV& dir, GHit& out, Counters& cnt) {
+    const qd_geom g = S.geoms[gi];
+    if (g.type == QD_GEOM_MESH) {
+        const MHit mh = mesh_query<STATS>(mesh_data(S), g.a, start, dir, false, 0., 1.);
+        if (STATS) { cnt.kd_nodes += mh.n_nodes; cnt.tris += mh.n_tris; cnt.mesh_queries += mh.n_nodes ? 1u : 0u; }
+        if (mh.tri < 0) return false;
+        out.dist = mh.dist; out.ip = start + dir * mh.dist; out.tri = mh.tri; out.mesh = g.a; out.l2 = mh.l2; out.l3 = mh.l3; out.dnd = 2;
+        return true;
+    }
+    if (g.type == QD_GEOM_HEIGHTFIELD) {
+        double dist = 0;
+        if (!hf_intersect<STATS>(S, g.a, start, dir, dist, cnt.kd_nodes, cnt.tris)) return false;
+        hf_finish(S, g.a, start, dir, dist, out);
+        return true;
+    }
+    return prim_intersect(g, start, dir, out);
+}
+
+template <bool STATS, int D>
+__device__ __attribute__((noinline)) bool csg_generic(const DScene& S, int gi, const DV& start, const DV& dir, GHit& out, Counters& cnt);
+
+template <bool STATS, int D>
+QD_DEV bool geom_any_intersect(const DScene& S, int gi, const DV& start, const DV& dir, GHit& out, Counters& cnt) {
+    if (S.geoms[gi].type == QD_GEOM_CSG) {
+        if constexpr (D > 0) return csg_generic<STATS, D - 1>(S, gi, start, dir, out, cnt);
+        else return false;
+    }
+    return leaf_any_intersect<STATS>(S, gi, start, dir, out, cnt);
+}
+
+// CsgOp::Intersect (src/geometry.cpp:184-234) for the CSG geometry gi whose operands may nest D more levels.
+template <bool STATS, int D>
+__device__ __attribute__((noinline)) bool csg_generic(const DScene& S, int gi, const DV& start, const DV& dir, GHit& out, Counters& cnt) {
+    const qd_geom g = S.geoms[gi];
+    GHit li, ri;
+    li.tri = ri.tri = -1;
+    bool inA = geom_inside_t<D>(S, g.a, start), inB = geom_inside_t<D>(S, g.b, start);
+    const bool cur = csg_op(g.c, inA, inB);
+    bool lhit = geom_any_intersect<STATS, D>(S, g.a, start, dir, li, cnt);
+    bool rhit = geom_any_intersect<STATS, D>(S, g.b, start, dir, ri, cnt);
+    while (lhit || rhit) {
+        if (lhit && (!rhit || li.dist <= ri.dist)) {
+            inA = !inA;
+            if (csg_op(g.c, inA, inB) != cur) { out = li; return true; }
+            const double prev = li.dist;
+            lhit = geom_any_intersect<STATS, D>(S, g.a, li.ip + dir * 1e-6, dir, li, cnt);
+            if (lhit) li.dist += prev + 1e-6;
+        } else if (rhit && (!lhit || ri.dist <= li.dist)) {
+            inB = !inB;
+            if (csg_op(g.c, inA, inB) != cur) { out = ri; return true; }
+            const double prev = ri.dist;
+            rhit = geom_any_intersect<STATS, D>(S, g.b, ri.ip + dir * 1e-6, dir, ri, cnt);
             if (rhit) ri.dist += prev + 1e-6;
         }
     }

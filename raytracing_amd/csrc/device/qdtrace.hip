@@ -142,7 +142,8 @@ struct LaneQueue {
 // kGeomCsg: CSG walk, kGeomPrim: sphere / cube / regular polygon).  qd_scene_create derives the mask from the scene and
 // launch() picks the kernel: what a scene does not hold is compiled out -- smaller live ranges, fewer spills around the
 // mesh query (the 10 M triangle scene, meshes + a plane: +9.5 %).
-constexpr int kGeomHf = 1, kGeomCsg = 2, kGeomPrim = 4, kGeomAll = 7;
+// kGeomCsgDeep: a CSG node whose operands are not all analytic primitives (another CSG, a mesh, a heightfield): csg_generic.
+constexpr int kGeomHf = 1, kGeomCsg = 2, kGeomPrim = 4, kGeomCsgDeep = 8, kGeomAll = 15;
 template <bool STATS, int GEOM>
 __device__ QD_OUTLINE int trace_nodes(const DScene& S, const DV& o, const DV& d, bool shadow, double target,
                        float& transp, double& best_dw, GHit& hit, Counters& cnt) {
@@ -185,7 +186,10 @@ __device__ QD_OUTLINE int trace_nodes(const DScene& S, const DV& o, const DV& d,
             got = hf_intersect<STATS>(S, g.a, r.o, r.d, dist, cnt.kd_nodes, cnt.tris);
         } else {
             GHit h;
-            got = analytic_intersect<(GEOM & kGeomCsg) != 0, (GEOM & kGeomPrim) != 0>(S, g, r.o, r.d, h);
+            if ((GEOM & kGeomCsgDeep) && g.type == QD_GEOM_CSG) {
+                Counters again = cnt;                       // the winner is intersected a second time: do not count that walk twice
+                got = csg_generic<STATS, kMaxCsgNesting - 1>(S, n.geom, r.o, r.d, h, final_pass ? again : cnt);
+            } else got = analytic_intersect<(GEOM & kGeomCsg) != 0, (GEOM & kGeomPrim) != 0>(S, g, r.o, r.d, h);
             cnt.t_c += QD_STAMP() - ta1;
             if (final_pass) { hit = h; break; }
             dist = h.dist;
@@ -910,7 +914,7 @@ struct qd_scene {
     unsigned long long* stats = nullptr; // 8 counters
     int* error_flag = nullptr;
     uint32_t spawn0 = 1, spawn1 = 1;     // tasks queued per hit at depth 0 / deeper
-    int geom_mask = 7;                   // kGeomHf | kGeomCsg | kGeomPrim as present in the scene: selects the kernel copy
+    int geom_mask = 7;                   // kGeomHf | kGeomCsg | kGeomPrim | kGeomCsgDeep as present in the scene: selects the kernel copy
     bool rich = true;                    // bitmap / Mandelbrot / procedural textures or bump maps present
     uint64_t kd_nodes = 0, kd_refs = 0, kd_leaves = 0, kd_max_leaf = 0;   // device tree after refinement
 };
@@ -1014,7 +1018,8 @@ int launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream) {
         static const Kernel rich[8] = {trace_kernel<false, 0, true>, trace_kernel<false, 1, true>, trace_kernel<false, 2, true>, trace_kernel<false, 3, true>,
                                        trace_kernel<false, 4, true>, trace_kernel<false, 5, true>, trace_kernel<false, 6, true>, trace_kernel<false, 7, true>};
         const Kernel kernel = g_counting ? trace_kernel<true, kGeomAll, true>                       // counting: one copy, all code
-                                         : (s->rich ? rich : plain)[s->geom_mask & kGeomAll];
+                            : (s->geom_mask & kGeomCsgDeep) ? trace_kernel<false, kGeomAll, true>    // CSG over CSG / mesh / heightfield: the copy with everything
+                                         : (s->rich ? rich : plain)[s->geom_mask & 7];
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, stream, s->d, P);
         HIP_TRY(hipGetLastError());
     }
@@ -1081,17 +1086,23 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
         const qd_geom& g = desc->geoms[i];
         if (g.type == QD_GEOM_CSG) {
             if (g.a < 0 || g.b < 0 || (uint32_t)g.a >= desc->n_geoms || (uint32_t)g.b >= desc->n_geoms) return set_err("qd_scene_create: CSG operand out of range");
-            for (int op : {g.a, g.b}) {
-                const int ot = desc->geoms[op].type;
-                if (ot == QD_GEOM_CSG || ot == QD_GEOM_MESH || ot == QD_GEOM_HEIGHTFIELD)
-                    return set_err("qd_scene_create: CSG operands must be analytic primitives on the device path (no nested CSG, mesh or heightfield operands)");
-            }
         } else if (g.type == QD_GEOM_MESH) {
             if (g.a < 0 || (uint32_t)g.a >= desc->n_meshes) return set_err("qd_scene_create: mesh index out of range");
         } else if (g.type == QD_GEOM_HEIGHTFIELD) {
             if (g.a < 0 || (uint32_t)g.a >= desc->n_hfields) return set_err("qd_scene_create: heightfield index out of range");
         } else if (g.type < 0 || g.type > QD_GEOM_HEIGHTFIELD) return set_err("qd_scene_create: unknown geometry type");
     }
+    // CSG trees: at most kMaxCsgNesting levels of CSG nodes (the device unrolls the recursion of CsgOp::Intersect); the depth
+    // bound also rejects cycles
+    std::function<int(int, int)> csg_depth = [&](int gi, int level) -> int {
+        const qd_geom& g = desc->geoms[gi];
+        if (g.type != QD_GEOM_CSG) return 0;
+        if (level >= kMaxCsgNesting) return kMaxCsgNesting + 1;
+        return 1 + std::max(csg_depth(g.a, level + 1), csg_depth(g.b, level + 1));
+    };
+    for (uint32_t i = 0; i < desc->n_geoms; ++i)
+        if (desc->geoms[i].type == QD_GEOM_CSG && csg_depth((int)i, 0) > kMaxCsgNesting)
+            return set_err("qd_scene_create: CSG geometries nested deeper than 4 levels (or a cycle)");
     for (uint32_t i = 0; i < desc->n_meshes; ++i) {
         const qd_mesh& m = desc->meshes[i];
         if ((uint64_t)m.tri_first + m.tri_count > desc->n_tris) return set_err("qd_scene_create: mesh triangle range out of bounds");
@@ -1103,11 +1114,26 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
         if ((n.meta & 3u) == 3u) { if (idx + n.count > desc->n_leaf_tris) return set_err("qd_scene_create: kd leaf range out of bounds"); }
         else if (idx + 1 >= desc->n_kd_nodes) return set_err("qd_scene_create: kd child out of bounds");
     }
-    {
-        uint32_t max_tris = 0;
-        for (uint32_t i = 0; i < desc->n_meshes; ++i) max_tris = std::max(max_tris, desc->meshes[i].tri_count);
-        for (uint64_t i = 0; i < desc->n_leaf_tris; ++i)
-            if (desc->leaf_tris[i] >= max_tris) return set_err("qd_scene_create: leaf triangle index out of bounds");
+    {   // every mesh's tree, walked from its root: a node is reached once (no cycles, no child shared between parents -- the
+        // refinement's descent would not terminate on those), and a leaf's references index the OWNING mesh's triangles
+        std::vector<uint8_t> seen(desc->n_kd_nodes, 0);
+        std::vector<uint64_t> todo;
+        for (uint32_t mi = 0; mi < desc->n_meshes; ++mi) {
+            const qd_mesh& m = desc->meshes[mi];
+            if (m.kd_root < 0) continue;
+            todo.assign(1, (uint64_t)m.kd_root);
+            while (!todo.empty()) {
+                const uint64_t i = todo.back(); todo.pop_back();
+                if (seen[i]) return set_err("qd_scene_create: kd tree has a cycle or a node with two parents");
+                seen[i] = 1;
+                const qd_kdnode& n = desc->kd_nodes[i];
+                const uint64_t idx = n.meta >> 2;
+                if ((n.meta & 3u) == 3u) {
+                    for (uint64_t k = 0; k < n.count; ++k)
+                        if (desc->leaf_tris[idx + k] >= m.tri_count) return set_err("qd_scene_create: leaf triangle index outside its mesh");
+                } else { todo.push_back(idx); todo.push_back(idx + 1); }
+            }
+        }
     }
     auto tex_ok = [&](int t) { return t >= -1 && t < (int)desc->n_textures; };
     for (uint32_t i = 0; i < desc->n_textures; ++i) {
@@ -1230,7 +1256,13 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     for (uint32_t i = 0; i < desc->n_geoms; ++i) {
         const int t = desc->geoms[i].type;
         if (t == QD_GEOM_HEIGHTFIELD) s->geom_mask |= kGeomHf;
-        else if (t == QD_GEOM_CSG) s->geom_mask |= kGeomCsg;
+        else if (t == QD_GEOM_CSG) {
+            s->geom_mask |= kGeomCsg;
+            for (int op : {desc->geoms[i].a, desc->geoms[i].b}) {
+                const int ot = desc->geoms[op].type;
+                if (ot == QD_GEOM_CSG || ot == QD_GEOM_MESH || ot == QD_GEOM_HEIGHTFIELD) s->geom_mask |= kGeomCsgDeep;
+            }
+        }
         else if (t != QD_GEOM_MESH && t != QD_GEOM_PLANE) s->geom_mask |= kGeomPrim;
     }
     s->rich = false;
@@ -1589,7 +1621,8 @@ extern "C" int qd_render_tiles_noalloc_async(qd_scene* s, const qd_camera* cam, 
                                     trace_kernel<false, 4, false>, trace_kernel<false, 5, false>, trace_kernel<false, 6, false>, trace_kernel<false, 7, false>};
     static const Kernel rich[8] = {trace_kernel<false, 0, true>, trace_kernel<false, 1, true>, trace_kernel<false, 2, true>, trace_kernel<false, 3, true>,
                                    trace_kernel<false, 4, true>, trace_kernel<false, 5, true>, trace_kernel<false, 6, true>, trace_kernel<false, 7, true>};
-    const Kernel kernel = g_counting ? trace_kernel<true, kGeomAll, true> : (s->rich ? rich : plain)[s->geom_mask & kGeomAll];
+    const Kernel kernel = g_counting ? trace_kernel<true, kGeomAll, true>
+                        : (s->geom_mask & kGeomCsgDeep) ? trace_kernel<false, kGeomAll, true> : (s->rich ? rich : plain)[s->geom_mask & 7];
     const uint32_t grid = P.n_units < waves ? P.n_units : waves;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, stream, s->d, P);
     HIP_TRY(hipGetLastError());

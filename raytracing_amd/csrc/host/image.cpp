@@ -333,19 +333,21 @@ bool load_exr(const char* path, Image& img, std::string& err) {
         const int32_t size = rd_i32(pos); pos += 4;
         if (size < 0 || !need((size_t)size)) { err = "loadEXR: truncated attribute"; return false; }
         const size_t a0 = pos;
+        const size_t a1 = a0 + (size_t)size;                  // end of this attribute (inside the file: checked above)
         if (name == "channels") {
             size_t q = a0;
-            while (q < a0 + (size_t)size && buf[q]) {
+            while (q < a1 && buf[q]) {
                 ExrChannel c;
-                while (buf[q]) c.name.push_back((char)buf[q++]);
+                while (q < a1 && buf[q]) c.name.push_back((char)buf[q++]);
+                if (q >= a1 || a1 - (q + 1) < 16) { err = "loadEXR: truncated channel list"; return false; }
                 ++q;
                 c.type = rd_i32(q); c.xs = rd_i32(q + 8); c.ys = rd_i32(q + 12);
                 q += 16;
                 chans.push_back(c);
             }
-        } else if (name == "compression") compression = buf[a0];
-        else if (name == "dataWindow") { for (int i = 0; i < 4; ++i) dw[i] = rd_i32(a0 + 4 * i); }
-        else if (name == "lineOrder") line_order = buf[a0];
+        } else if (name == "compression") { if (size < 1) { err = "loadEXR: bad compression attribute"; return false; } compression = buf[a0]; }
+        else if (name == "dataWindow") { if (size < 16) { err = "loadEXR: bad dataWindow attribute"; return false; } for (int i = 0; i < 4; ++i) dw[i] = rd_i32(a0 + 4 * i); }
+        else if (name == "lineOrder") { if (size < 1) { err = "loadEXR: bad lineOrder attribute"; return false; } line_order = buf[a0]; }
         pos = a0 + (size_t)size;
     }
     (void)line_order;

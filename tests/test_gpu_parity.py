@@ -20,7 +20,7 @@ SUM_ORDER_TOL = 2e-6       # two device renders of the same pixel: float additio
 
 SCENES = ["hw9/nonconvex.qdmg", "hw9/axe_test.qdmg", "hw9/testmesh.qdmg", "hw9/dragon.qdmg", "window_fixed.qdmg", "bumpmap_fixed.qdmg", "lecture7_fixed.qdmg",
           "heightfield_fixed.qdmg", "kdtree_teapot_lowres_env.qdmg", "kdtree_teapot_hires_sah_noenv.qdmg",
-          "kdtree_fixed.qdmg"]
+          "kdtree_fixed.qdmg", "all_classes.qdmg", "ref_pin.qdmg", "csg_generic.qdmg"]
 
 
 @pytest.fixture(scope="module", autouse=True)

@@ -210,3 +210,24 @@ def test_synthetic_scene_vertex_buffer_is_the_committed_one(data_dir, synthetic_
         assert synthetic_vertex_sha256(s) == synthetic_sha[f"n{n}"]["sha256"]
     finally:
         s.close()
+
+
+def test_truncated_or_malformed_exr_is_an_error_not_a_crash(data_dir, tmp_path):
+    """The EXR reader bounds every header read by the attribute it is in: cutting a file anywhere in its header, or
+    declaring attributes shorter than their fixed layout, must come back as an error."""
+    src = open(os.path.join(data_dir, "env", "forest", "posx.exr"), "rb").read()
+    good = host.load_image(os.path.join(data_dir, "env", "forest", "posx.exr"))
+    assert good.shape == (256, 256, 3)
+    at = src.index(b"channels\0chlist\0")
+    size_at = at + len(b"channels\0chlist\0")
+    cases = [src[:n] for n in (4, 9, at + 5, size_at + 2, size_at + 4 + 3, size_at + 4 + 20, 400)]
+    cut = bytearray(src); cut[size_at:size_at + 4] = (5).to_bytes(4, "little")      # channel list shorter than one entry
+    cases.append(bytes(cut))
+    dwat = src.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0")
+    bad = bytearray(src); bad[dwat:dwat + 4] = (3).to_bytes(4, "little")             # dataWindow of 3 bytes
+    cases.append(bytes(bad))
+    for i, blob in enumerate(cases):
+        p = tmp_path / f"bad{i}.exr"
+        p.write_bytes(blob)
+        with pytest.raises(RuntimeError):
+            host.load_image(str(p))
