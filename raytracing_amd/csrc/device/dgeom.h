@@ -363,7 +363,7 @@ QD_DEV double box_closest(const double* mn, const double* mx, const DV& start, c
             const double x = comp(start, u) + comp(dir, u) * dist;
             if (is_between(x, mn[u], mx[u], 0)) {
                 const double y = comp(start, v) + comp(dir, v) * dist;
-                if (is_between(y, mn[v], mx[v], 0)) best = fmin(best, dist);
+                if (is_between(y, mn[v], mx[v], 0)) best = smin(best, dist);
             }
         }
     }
@@ -405,7 +405,7 @@ QD_DEV bool hf_intersect(const DScene& S, int hf, const DV& start, const DV& dir
         int x0 = (int)floor(p.x), z0 = (int)floor(p.z);
         if (!(x0 < 0 || x0 >= W || z0 < 0 || z0 >= H) && h.use_optimization) {
             int k = 0;
-            while (k < h.max_k && fmin(p.y, p.y + dir.y * (1 << k)) > (double)highmap[((size_t)z0 * W + x0) * 16 + k]) ++k;
+            while (k < h.max_k && smin(p.y, p.y + dir.y * (1 << k)) > (double)highmap[((size_t)z0 * W + x0) * 16 + k]) ++k;
             --k;
             if (k >= 0) {
                 p = p + dir * (1 << k);
@@ -415,8 +415,8 @@ QD_DEV bool hf_intersect(const DScene& S, int hf, const DV& start, const DV& dir
         if (x0 < 0 || x0 >= W || z0 < 0 || z0 >= H) break;
         const double lx = dir.x > 0 ? (ceil(p.x) - p.x) * mx : (floor(p.x) - p.x) * mx;
         const double lz = dir.z > 0 ? (ceil(p.z) - p.z) * mz : (floor(p.z) - p.z) * mz;
-        const DV p_next = p + step * (fmin(lx, lz) + 1e-6);
-        if (fmin(p.y, p_next.y) < (double)maxh[(size_t)z0 * W + x0]) {
+        const DV p_next = p + step * (smin(lx, lz) + 1e-6);
+        if (smin(p.y, p_next.y) < (double)maxh[(size_t)z0 * W + x0]) {
             double closest = kInf;
             if (STATS) ++n_cells;
             const DV A = mk(x0, get_height(x0, z0), z0);

@@ -30,6 +30,10 @@ QD_DEV double len(const DV& a) { return dsqrt(a.x * a.x + a.y * a.y + a.z * a.z)
 QD_DEV DV normalize(DV a) { const double m = 1. / len(a); a.x *= m; a.y *= m; a.z *= m; return a; }
 QD_DEV double comp(const DV& a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 QD_DEV double sqr(double a) { return a * a; }
+// std::min / std::max as the reference calls them: (b < a) ? b : a and (a < b) ? b : a.  Unlike fmin / fmax they hand a NaN
+// first argument through, which decides where the heightfield DDA of a ray with dir.x == 0 on a grid line stops.
+QD_DEV double smin(double a, double b) { return b < a ? b : a; }
+QD_DEV double smax(double a, double b) { return a < b ? b : a; }
 template <class P> QD_DEV DV ld3(P p) { return mk(p[0], p[1], p[2]); }
 QD_DEV DV mul_mat(const DV& v, const double* m) {
     return mk(v.x * m[0] + v.y * m[3] + v.z * m[6], v.x * m[1] + v.y * m[4] + v.z * m[7], v.x * m[2] + v.y * m[5] + v.z * m[8]);

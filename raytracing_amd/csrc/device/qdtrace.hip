@@ -260,7 +260,7 @@ __device__ QD_OUTLINE void eval_leaf_shader(const DScene& S, const Params& P, in
                     const double LdotV = dot(lightDir, -ray.d);
                     const double LdotN = dot(lightDir, info.normal);
                     const double sv = LdotV - LdotN * VdotN;
-                    const double t = (sv <= 0. ? 1. : fmax(LdotN, VdotN));
+                    const double t = (sv <= 0. ? 1. : smax(LdotN, VdotN));
                     const double a = 1 - 0.5 * sigma2 / (sigma2 + 0.33);
                     const double b = 0.45 * sigma2 / (sigma2 + 0.09);
                     cl = diffuse * (float)(LdotN * (a + b * sv / t));
@@ -277,7 +277,7 @@ __device__ QD_OUTLINE void eval_leaf_shader(const DScene& S, const Params& P, in
                     } else if (sh.type == QD_SH_BLINNPHONG) {                      // :93-100
                         const DV ld = normalize(lpos - info.ip);
                         const DV half = normalize(ld - ray.d);
-                        const double spec = pow(fmax(dot(info.normal, half), 0.), sh.p1);
+                        const double spec = pow(smax(dot(info.normal, half), 0.), sh.p1);
                         cl = cl + mkc(1.f, 1.f, 1.f) * (float)spec * (float)sh.p0;
                     }
                 }

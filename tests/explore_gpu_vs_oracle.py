@@ -39,6 +39,9 @@ for name in scenes:
         "nan_gpu": int(np.isnan(rgb).sum()), "nan_cpu": int(np.isnan(orgb).sum()),
         "gpu_stats": {k: v for k, v in st.items()}, "cpu_stats": ost,
     }
+    bad = np.argwhere((hn != ohn) | (ht != oht) | (hd.view(np.uint64) != ohd.view(np.uint64)))
+    res["mismatches"] = [{"x": int(x), "y": int(y), "gpu": [int(hn[y, x]), int(ht[y, x]), float(hd[y, x])],
+                          "cpu": [int(ohn[y, x]), int(oht[y, x]), float(ohd[y, x])]} for y, x in bad[:40]]
     out[name] = res
     print(name, json.dumps(res), flush=True)
     ds.close()
