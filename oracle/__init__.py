@@ -49,6 +49,10 @@ def lib():
         L.orc_camera_rays.argtypes = [P(abi.QdSceneDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_trace_rays.restype = C.c_int
         L.orc_trace_rays.argtypes = [P(abi.QdSceneDesc), C.c_size_t, C.c_void_p, C.c_void_p]
+        L.orc_random01_bulk.restype = None
+        L.orc_random01_bulk.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_pixel_paths.restype = None
+        L.orc_pixel_paths.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p]
         L.orc_unit_funcs.restype = C.c_int
         L.orc_unit_funcs.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p]
         _LIB = L

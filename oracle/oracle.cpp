@@ -1066,3 +1066,13 @@ extern "C" int orc_unit_funcs(size_t n, const double* in, double* out) {
     }
     return 0;
 }
+
+// The path-hashed random stream of rng_mode 1 (what the device draws for glossy reflection), exposed for the
+// statistical tests: out[i] = random01(path[i], sample[i], draw[i]); pixel_paths gives the path ids of camera rays.
+extern "C" void orc_random01_bulk(size_t n, const uint32_t* path, const uint32_t* sample, const uint32_t* draw, double* out) {
+    Ctx c; memset(&c, 0, sizeof c); c.rng_mode = 1;
+    for (size_t i = 0; i < n; ++i) out[i] = random01(c, path[i], sample[i], draw[i]);
+}
+extern "C" void orc_pixel_paths(size_t n, const int32_t* xy, uint32_t* out) {
+    for (size_t i = 0; i < n; ++i) out[i] = pixel_path(xy[i * 2], xy[i * 2 + 1], 0);
+}

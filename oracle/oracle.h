@@ -43,6 +43,10 @@ int orc_camera_rays(const qd_scene_desc* S, int x0, int y0, int x1, int y1, doub
 int orc_trace_rays(const qd_scene_desc* S, size_t n, const double* rays, void* out_records);
 int orc_unit_funcs(size_t n, const double* in, double* out);
 
+/* rng_mode 1's stream, for the statistical tests of the glossy sampler (tests/test_glossy_statistics.py). */
+void orc_random01_bulk(size_t n, const uint32_t* path, const uint32_t* sample, const uint32_t* draw, double* out);
+void orc_pixel_paths(size_t n, const int32_t* xy, uint32_t* out);
+
 #ifdef __cplusplus
 }
 #endif
