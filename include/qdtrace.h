@@ -320,6 +320,33 @@ int qd_scene_bind_stream(qd_scene* scene, int max_trace_depth, void* hip_stream)
 int qd_untile_async(const float* src_dev, float* dst_dev, int width, int height,
                     int tile, int tile_stride, int tiles_per_rank_padded, void* hip_stream);
 
+/* ----------------------------------------------------------------------------
+ * Multi-GPU (one process per GPU; RCCL over xGMI).  Replaces: nothing in the reference (one render thread, one
+ * process, src/sdl.cpp:194-233); SURVEY.md 8(e): the image shards by tiles, scene buffers are replicated, the
+ * framebuffer is gathered to rank 0.  A C / C++ host does:
+ *   rank 0: qd_comm_unique_id(id), hands the 128 bytes to the other ranks (MPI, a socket, a file ...);
+ *   every rank: qd_init(local device), qd_comm_create(id, rank, world, &comm), qd_scene_create(...);
+ *   per frame, every rank: qd_render_tiles_async(scene, ..., tile, rank, world, shard_dev, ...) then
+ *                          qd_gather_frame_async(comm, shard_dev, gathered_dev, frame_dev, W, H, tile, stream);
+ * rank 0's frame_dev holds the frame once the stream has drained.  qd_init(device) binds a process to ONE GPU
+ * (SURVEY's sketch had qd_init(n_devices) for a single process driving all GPUs; one process per GPU is this build's
+ * model, so the device ordinal is the argument and the world is formed by qd_comm_create).
+ * -------------------------------------------------------------------------- */
+typedef struct qd_comm qd_comm;
+int qd_comm_unique_id(uint8_t id_out[128]);                                      /* ncclGetUniqueId */
+int qd_comm_create(const uint8_t id[128], int rank, int world, qd_comm** out);   /* ncclCommInitRank on the qd_init device; collective over all ranks */
+int qd_comm_destroy(qd_comm* comm);
+/* `count` floats of every rank -> dst_dev[r * count] on rank 0 (dst_dev ignored elsewhere): grouped ncclSend / ncclRecv,
+ * each peer straight to the root.  Rank 0 may produce its block in place (src_dev == dst_dev).  Enqueue only. */
+int qd_comm_gather_async(qd_comm* comm, const float* src_dev, float* dst_dev, size_t count, void* hip_stream);
+/* rank 0's buffer -> every rank (the AA pass hands the assembled first-pass frame back out).  Enqueue only. */
+int qd_comm_broadcast_async(qd_comm* comm, float* buf_dev, size_t count, void* hip_stream);
+/* The exchange step of a frame: every rank's compacted shard (tiles_per_rank_padded = ceil(n_tiles / world) tiles of
+ * tile*tile*3 floats) -> gathered_dev on rank 0 (world such blocks), then the de-interleave kernel writes frame_dev
+ * (width*height*3 floats, row-major).  gathered_dev / frame_dev are ignored on the other ranks.  Enqueue only. */
+int qd_gather_frame_async(qd_comm* comm, const float* shard_dev, float* gathered_dev, float* frame_dev,
+                          int width, int height, int tile, void* hip_stream);
+
 /* Replaces: Color::toRGB32 / ConvertTo8Bit (src/color.cpp:16-24, src/utils.h:22,34):
  * clamp, floor(x*255+0.5); rgb float image (device) -> packed 8-bit B,G,R rows
  * bottom-up as Bitmap::SaveBMP writes them (src/bitmap.cpp:209-217). */

@@ -1669,3 +1669,5 @@ extern "C" int qd_scene_check(qd_scene* s) {
     if (f) { (void)hipMemset(s->error_flag, 0, sizeof(int)); return set_err("ray queue overflow on device"); }
     return 0;
 }
+
+#include "qdcomm.h"

@@ -8,6 +8,7 @@ from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIB_OVERRIDE = None          # development only: scripts/ A/B another build of the same kernels through use_library()
 _INIT_DEVICE = None
 
 
@@ -18,7 +19,7 @@ class DeviceError(RuntimeError):
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.environ.get("QDTRACE_LIB") or os.path.join(_HERE, "lib", "libqdtrace.so")   # override: A/B builds of the same kernels
+        path = _LIB_OVERRIDE or os.path.join(_HERE, "lib", "libqdtrace.so")
         if not os.path.exists(path):
             raise DeviceError(f"{path} is missing: the HIP extension was not built (python -m raytracing_amd.build device)")
         L = C.CDLL(path)
@@ -45,11 +46,26 @@ def lib():
         L.qd_pack_rgb32_async.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.qd_set_kd_refine.argtypes = [C.c_int, C.c_double]
         L.qd_scene_kd_info.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
+        L.qd_comm_unique_id.argtypes = [C.c_void_p]
+        L.qd_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
+        L.qd_comm_destroy.argtypes = [C.c_void_p]
+        L.qd_comm_gather_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.qd_comm_broadcast_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.qd_gather_frame_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         for name in abi.QDTRACE_SYMBOLS:
             if name not in ("qd_last_error", "qd_shutdown", "qd_scene_destroy"):
                 getattr(L, name).restype = C.c_int
         _LIB = L
     return _LIB
+
+
+def use_library(path):
+    """Development aid for scripts/ (A/B of kernel builds): load `path` instead of the in-tree library.  Must be called
+    before the first use; the product never calls it and no environment variable reaches it."""
+    global _LIB_OVERRIDE
+    if _LIB is not None:
+        raise DeviceError("use_library: the device library is already loaded")
+    _LIB_OVERRIDE = path
 
 
 def _check(rc, what):
@@ -221,3 +237,44 @@ def pack_rgb32_async(rgb_ptr, pitch_floats, out_ptr, width, height, use_srgb=Fal
     """Color::toRGB32 / toSRGB32 per pixel of a device image (what DisplayVFBRect shows)."""
     _check(lib().qd_pack_rgb32_async(C.c_void_p(rgb_ptr), pitch_floats, C.c_void_p(out_ptr), width, height, 1 if use_srgb else 0,
                                      shifts[0], shifts[1], shifts[2], C.c_void_p(stream or 0)), "qd_pack_rgb32_async")
+
+
+class Comm:
+    """RCCL communicator of this process' GPU (qd_comm_create): one process per GPU.  `exchange(id_bytes_or_None)` is how
+    the 128-byte unique id travels from rank 0 to the others: it is called with rank 0's id on rank 0 and with None
+    elsewhere, and returns the id on every rank (torch.distributed, MPI, a file -- the library does not care)."""
+
+    def __init__(self, rank, world, exchange=None):
+        if _INIT_DEVICE is None:
+            raise DeviceError("Comm: device.init(local_device) first")
+        self.rank, self.world = rank, world
+        uid = None
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            _check(lib().qd_comm_unique_id(buf), "qd_comm_unique_id")
+            uid = bytes(buf)
+        if world > 1:
+            if exchange is None:
+                raise DeviceError("Comm: world > 1 needs an `exchange` callable for the unique id")
+            uid = exchange(uid)
+        if not isinstance(uid, (bytes, bytearray)) or len(uid) != 128:
+            raise DeviceError("Comm: the exchanged unique id must be 128 bytes")
+        h = C.c_void_p()
+        idbuf = (C.c_uint8 * 128).from_buffer_copy(bytes(uid))
+        _check(lib().qd_comm_create(idbuf, rank, world, C.byref(h)), "qd_comm_create")
+        self._h = h
+
+    def gather_async(self, src_ptr, dst_ptr, count, stream=None):
+        _check(lib().qd_comm_gather_async(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr or 0), count, C.c_void_p(stream or 0)), "qd_comm_gather_async")
+
+    def broadcast_async(self, buf_ptr, count, stream=None):
+        _check(lib().qd_comm_broadcast_async(self._h, C.c_void_p(buf_ptr), count, C.c_void_p(stream or 0)), "qd_comm_broadcast_async")
+
+    def gather_frame_async(self, shard_ptr, gathered_ptr, frame_ptr, width, height, tile, stream=None):
+        _check(lib().qd_gather_frame_async(self._h, C.c_void_p(shard_ptr), C.c_void_p(gathered_ptr or 0), C.c_void_p(frame_ptr or 0),
+                                           width, height, tile, C.c_void_p(stream or 0)), "qd_gather_frame_async")
+
+    def close(self):
+        if self._h:
+            lib().qd_comm_destroy(self._h)
+            self._h = None

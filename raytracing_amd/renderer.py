@@ -20,7 +20,7 @@ class _Slot:
         self.stats = torch.zeros(8, dtype=torch.int64, device=dev)   # qd_stats: 7 counters + kernel_ms slot
         self.frame = torch.zeros((fr.H, fr.W, 3), dtype=torch.float32, device=dev) if fr.rank == 0 else None
         self.gathered = (torch.zeros((world, fr.tpr, tile, tile, 3), dtype=torch.float32, device=dev)
-                         if (fr.rank == 0 and world > 1) else None)
+                         if (fr.rank == 0 and fr.exchange) else None)
 
 
 class FrameRenderer:
@@ -28,9 +28,16 @@ class FrameRenderer:
     (inside the library, qd_scene_bind_stream) working set, so that consecutive frames overlap on the GPU: a frame's
     last ray generations keep only a few waves busy and the next frame's pixels fill the rest of the chip."""
 
-    def __init__(self, scene, tile=32, rank=0, world=1, local_device=0, frames_in_flight=1):
-        if not 1 <= frames_in_flight <= 8:
-            raise ValueError("frames_in_flight must be 1..8 (working sets per scene in libqdtrace)")
+    def __init__(self, scene, tile=32, rank=0, world=1, local_device=0, frames_in_flight=1, collectives="rccl",
+                 force_collectives=False):
+        """collectives: "rccl" = the library's own exchange step (qd_comm_*: grouped ncclSend / ncclRecv to rank 0 behind
+        the C-ABI; the unique id travels over torch.distributed's process group), "torch" = torch.distributed.gather /
+        broadcast, "none" = no exchange at all (rehearsals that time one rank's shard on a lone GPU).  force_collectives
+        runs the exchange even at world 1 (a one-rank communicator: tests)."""
+        if not 1 <= frames_in_flight <= 7:
+            raise ValueError("frames_in_flight must be 1..7 (libqdtrace keeps 8 working sets per scene, one of them the default stream's)")
+        if collectives not in ("rccl", "torch", "none"):
+            raise ValueError("collectives must be 'rccl', 'torch' or 'none'")
         self.scene, self.tile, self.rank, self.world = scene, tile, rank, world
         self.dev = torch.device("cuda", local_device)
         torch.cuda.set_device(self.dev)
@@ -40,6 +47,10 @@ class FrameRenderer:
         self.W, self.H = st.frame_width, st.frame_height
         self.tpr = sharding.tiles_per_rank_padded(self.W, self.H, tile, world)
         self.F = frames_in_flight
+        self.exchange = (world > 1 or force_collectives) and collectives != "none"
+        self.comm = None
+        if self.exchange and collectives == "rccl":
+            self.comm = device.Comm(rank, world, exchange=self._exchange_id if world > 1 else None)
         self.slots = [_Slot(self, torch.cuda.Stream(self.dev) if self.F > 1 else None) for _ in range(self.F)]
         for sl in self.slots:
             if sl.stream is not None:
@@ -55,14 +66,31 @@ class FrameRenderer:
         self.dscene.render_tiles_async(sl.shard.data_ptr(), self.tile, self.rank, self.world,
                                        stats_dev_ptr=sl.stats.data_ptr(), stream=stream)
 
+    def _exchange_id(self, uid):
+        """rank 0's 128-byte RCCL unique id -> every rank, over the torch.distributed group the launcher set up."""
+        import torch.distributed as dist
+        on_gpu = dist.get_backend() == "nccl"
+        t = torch.zeros(128, dtype=torch.uint8, device=self.dev if on_gpu else "cpu")
+        if uid is not None:
+            t.copy_(torch.frombuffer(bytearray(uid), dtype=torch.uint8))
+        dist.broadcast(t, src=0)
+        return bytes(t.cpu().numpy().tobytes())
+
     # The collectives, in one place (tests on a one-GPU box swap these two for host-staged gloo).
     def _coll_gather(self, src, dst):
-        """src of every rank -> dst[r] on rank 0 (dst is None elsewhere).  RCCL sends each peer's block straight to the
+        """src of every rank -> dst[r] on rank 0 (dst is None elsewhere).  Each peer's block goes straight to the
         root over that peer's own xGMI link, not around a ring."""
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        if self.comm is not None:
+            self.comm.gather_async(src.data_ptr(), dst.data_ptr() if self.rank == 0 else 0, src.numel(), stream=stream)
+            return
         import torch.distributed as dist
         dist.gather(src, list(dst.unbind(0)) if self.rank == 0 else None, dst=0)
 
     def _coll_broadcast(self, t):
+        if self.comm is not None:
+            self.comm.broadcast_async(t.data_ptr(), t.numel(), stream=torch.cuda.current_stream(self.dev).cuda_stream)
+            return
         import torch.distributed as dist
         dist.broadcast(t, src=0)
 
@@ -73,12 +101,14 @@ class FrameRenderer:
         """The one exchange step: compacted shards -> rank 0, then de-interleave."""
         sl = self.slots[slot]
         stream = torch.cuda.current_stream(self.dev).cuda_stream
-        if self.world > 1:
+        if self.exchange:
             self._gather_shards(sl)
             if self.rank != 0:
                 return None
             src = sl.gathered
         else:
+            if self.world > 1:
+                raise RuntimeError("FrameRenderer(collectives='none') has one rank's shard only: there is no frame to assemble")
             src = sl.shard
         device.untile_async(src.data_ptr(), sl.frame.data_ptr(), self.W, self.H, self.tile, self.world, self.tpr,
                             stream=stream)
@@ -119,7 +149,7 @@ class FrameRenderer:
         if not want:
             return frame
         cur = torch.cuda.current_stream(self.dev)
-        if self.world == 1:
+        if not self.exchange:
             cur.synchronize()
             self.dscene.antialias_device(frame.data_ptr())
             return frame

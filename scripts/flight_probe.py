@@ -15,7 +15,7 @@ K = 12
 scene = host.Scene.synthetic(n, 42, 3840, 2160, 8, os.path.join(ROOT, "tests/golden/data/env/forest"))
 base = {}
 for world in worlds:
-    fr = renderer.FrameRenderer(scene, tile=32, rank=0, world=world, local_device=0, frames_in_flight=max(2, FMAX))
+    fr = renderer.FrameRenderer(scene, tile=32, rank=0, world=world, local_device=0, frames_in_flight=max(2, FMAX), collectives="none")
     for F in range(1, FMAX + 1):
         for rep in range(2):
             torch.cuda.synchronize()

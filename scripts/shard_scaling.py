@@ -11,7 +11,7 @@ base = None
 worlds = tuple(int(x) for x in sys.argv[2].split(',')) if len(sys.argv) > 2 else (1, 2, 4, 8)
 for world in worlds:
     for rank in sorted({0, world - 1}):
-        fr = renderer.FrameRenderer(scene, tile=32, rank=rank, world=world, local_device=0)
+        fr = renderer.FrameRenderer(scene, tile=32, rank=rank, world=world, local_device=0, collectives="none")
         for _ in range(2):
             fr.render_shard()
         torch.cuda.synchronize()

@@ -496,3 +496,60 @@ def test_specialised_kernel_copy_equals_the_all_code_copy(load_scene, data_dir, 
     # float additions land in a different order in the two runs; a glossy pixel sums 25+ samples of magnitude > 1
     assert np.abs(rgb0 - rgb1).max() <= 5 * SUM_ORDER_TOL
     assert st0["rays"] == st1["rays"] and st0["shadow_rays"] == st1["shadow_rays"]
+
+
+def test_rccl_exchange_step_runs_at_world_one(load_scene):
+    """The library's own exchange step (qd_comm_create -> ncclCommInitRank, qd_gather_frame_async -> grouped ncclSend /
+    ncclRecv + de-interleave, qd_comm_broadcast_async) as far as one GPU allows: a one-rank communicator, frames in flight
+    on side streams, the AA pass through broadcast + tap gather.  Every frame must be the frame of a lone qd_render."""
+    from raytracing_amd import renderer
+    s = load_scene("hw9/nonconvex.qdmg")
+    old = _aa_settings(s, want_aa=0)
+    try:
+        fr = renderer.FrameRenderer(s, tile=32, rank=0, world=1, local_device=0, frames_in_flight=3, collectives="rccl",
+                                    force_collectives=True)
+        try:
+            assert fr.comm is not None and fr.exchange
+            ref, _, _ = fr.dscene.render()
+            slots = [fr.submit_frame() for _ in range(5)][-3:]
+            for k in slots:
+                assert np.abs(fr.wait(k).cpu().numpy() - ref).max() <= SUM_ORDER_TOL
+            fr.check()
+            # AA pass over the collectives: frame broadcast, taps traced by "every" rank, taps gathered, replace rule on rank 0
+            _aa_settings(s, want_aa=1, want_adaptive_aa=1, show_aa=0)
+            frame = fr.render_frame().cpu().numpy()
+            fr.check()
+            ref_aa, _ = fr.dscene.render_frame()
+            assert np.abs(frame - ref_aa).max() <= SUM_ORDER_TOL
+            assert np.abs(frame - ref).max() > 1e-3
+        finally:
+            fr.comm.close()
+            fr.dscene.close()
+    finally:
+        _aa_settings(s, **old)
+
+
+def test_rccl_gather_through_the_c_abi_directly():
+    """qd_comm_gather_async / qd_gather_frame_async called like a C host would: raw device pointers, one rank."""
+    import torch
+    device.init(0)
+    comm = device.Comm(0, 1)
+    try:
+        W, H, tile = 100, 70, 32
+        tpr = sharding.tiles_per_rank_padded(W, H, tile, 1)
+        rng = np.random.default_rng(1)
+        shard = torch.from_numpy(rng.random((tpr, tile, tile, 3), dtype=np.float32)).cuda()
+        gathered = torch.zeros((1, tpr, tile, tile, 3), dtype=torch.float32, device="cuda:0")
+        frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        comm.gather_frame_async(shard.data_ptr(), gathered.data_ptr(), frame.data_ptr(), W, H, tile, stream=st.cuda_stream)
+        st.synchronize()
+        assert np.array_equal(gathered.cpu().numpy()[0], shard.cpu().numpy())
+        assert np.array_equal(frame.cpu().numpy(), sharding.untile(shard.cpu().numpy()[None], W, H, tile, 1))
+        buf = torch.arange(1000, dtype=torch.float32, device="cuda:0")
+        comm.broadcast_async(buf.data_ptr(), buf.numel())
+        torch.cuda.synchronize()
+        assert np.array_equal(buf.cpu().numpy(), np.arange(1000, dtype=np.float32))
+    finally:
+        comm.close()

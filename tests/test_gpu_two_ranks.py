@@ -58,7 +58,7 @@ def _worker(rank, world, port, flight, out_path, aa=False):
             dist.broadcast(h, src=0)
             t.copy_(h)
 
-    fr = HostGather(s, tile=32, rank=rank, world=world, local_device=0, frames_in_flight=flight)
+    fr = HostGather(s, tile=32, rank=rank, world=world, local_device=0, frames_in_flight=flight, collectives="torch")
     note("scene on device")
     if aa:
         frame = fr.render_frame()
