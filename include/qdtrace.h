@@ -366,6 +366,14 @@ int qd_pack_rgb32_async(const float* rgb_dev, size_t row_pitch_floats, uint32_t*
  * nbIntersections, src/mesh.cpp:20-22); off by default because the counters cost registers. */
 int qd_set_counting(int on);
 
+/* Replaces: nothing in the reference (its Raytrace recursion has one form).  Selects how a frame is scheduled on the GPU:
+ * 0 = one persistent kernel, every lane with its own LIFO queue of ray tasks (memory bounded by queue depth x lanes);
+ * 1 = wavefront pipeline: generations of rays in HBM queues, a traversal kernel that refills idle lanes inside its loop
+ *     and a shading kernel per generation (queues sized pixels x max(4, tasks per hit + 1); a generation that outgrows
+ *     them raises the scene's error flag, see qd_scene_check).  Same arithmetic, same results up to the order of float
+ * additions.  Applies to calls made after it. */
+int qd_set_pipeline(int pipeline);
+
 /* Replaces: the leaf criterion of Mesh::BuildKD (src/mesh.cpp:218, TRIANGLES_PER_LEAF = 20 in
  * src/constants.h:14) for the DEVICE copy of the tree only.  qd_scene_create keeps the caller's
  * tree and splits each of its leaves further with a surface-area heuristic until a leaf holds at most

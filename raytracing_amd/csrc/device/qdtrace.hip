@@ -83,6 +83,8 @@ struct Params {
                                          // the number of waves of this pass that have left
     const uint64_t* in_list; const uint32_t* in_count;     // source 1: tasks, word-major (word w of task i at [w * list_cap + i]);
     uint64_t* out_list; uint32_t* out_count; size_t list_cap;   // eight regions of list_cap / 8 tasks with a count each
+    // wavefront pipeline (wavefront.h): two ray queues (generations alternate), hit records, control words, deep KD stack levels
+    uint64_t* wf_ray[2]; uint64_t* wf_hit; uint32_t* wf_ctl; uint2* wf_deep; uint32_t wf_cap;
 };
 
 struct Task {
@@ -233,18 +235,19 @@ QD_DEV void assemble_info(const DScene& S, const qd_node& n, GHit& h, double dw,
 // One non-layered shader at a hit: adds its direct colour to acc and queues its rays
 // (Lambert/Phong/BlinnPhong/OrenNayar/Const/Reflection/Refraction::Shade, src/shading.cpp).
 constexpr int kMaxLayerNesting = 4;      // Layered inside Layered ...: levels below the node's own shader (qd_scene_create checks)
-template <bool RICH>
+template <bool RICH, class Queue>
 __device__ QD_OUTLINE void eval_nested_layered(const DScene& S, const Params& P, const qd_shader& top, Col w, uint32_t slot, const Task& ray,
-                                               uint32_t depth, const Info& info, Col& acc, LaneQueue& q);
+                                               uint32_t depth, const Info& info, Col& acc, Queue& q);
 
 // NESTED: a Layered shader met here (a layer that is itself Layered) goes to eval_nested_layered, which walks the inner
 // layers with an explicit stack and calls the NESTED = false copy for the leaves -- no recursion on the device.
-template <bool NESTED, bool RICH>
+// Queue: where child rays go -- the lane's LIFO queue (one-kernel form) or the next generation's queue (wavefront form).
+template <bool NESTED, bool RICH, class Queue>
 __device__ QD_OUTLINE void eval_leaf_shader(const DScene& S, const Params& P, int si, Col w, uint32_t slot, const Task& ray, uint32_t depth,
-                             const Info& info, Col& acc, LaneQueue& q) {
+                             const Info& info, Col& acc, Queue& q) {
     const qd_shader sh = S.shaders[si];
     switch (sh.type) {
-        case QD_SH_LAYERED: if (NESTED) eval_nested_layered<RICH>(S, P, sh, w, slot, ray, depth, info, acc, q); break;
+        case QD_SH_LAYERED: if (NESTED) eval_nested_layered<RICH, Queue>(S, P, sh, w, slot, ray, depth, info, acc, q); break;
         case QD_SH_CONST: acc = acc + w * ldc(sh.color); break;
         case QD_SH_LAMBERT: case QD_SH_PHONG: case QD_SH_BLINNPHONG: case QD_SH_ORENNAYAR: {
             const Col diffuse = sh.tex >= 0 ? tex_sample<RICH>(S, sh.tex, info) : ldc(sh.color);
@@ -349,9 +352,9 @@ __device__ QD_OUTLINE void eval_leaf_shader(const DScene& S, const Params& P, in
 
 // Layered::Shade (src/shading.cpp:260-275) for a Layered that is a layer of another one: the same suffix-product walk as
 // in the kernel, one stack frame per nesting level.  A layer's path-id slot is parent_slot * 32 + i + 1 (the oracle's rule).
-template <bool RICH>
+template <bool RICH, class Queue>
 __device__ QD_OUTLINE void eval_nested_layered(const DScene& S, const Params& P, const qd_shader& top, Col w, uint32_t slot, const Task& ray,
-                                               uint32_t depth, const Info& info, Col& acc, LaneQueue& q) {
+                                               uint32_t depth, const Info& info, Col& acc, Queue& q) {
     struct Frame { int i0, i; uint32_t slot; Col w, suffix; };
     Frame st[kMaxLayerNesting];
     int sp = 0;
@@ -370,7 +373,7 @@ __device__ QD_OUTLINE void eval_nested_layered(const DScene& S, const Params& P,
         if (inner.type == QD_SH_LAYERED) {
             if (sp + 1 < kMaxLayerNesting) { ++sp; st[sp] = Frame{inner.i0, inner.i1 - 1, child_slot, wl, mkc(1.f, 1.f, 1.f)}; }
         } else {
-            eval_leaf_shader<false, RICH>(S, P, l.shader, wl, child_slot, ray, depth, info, acc, q);
+            eval_leaf_shader<false, RICH, Queue>(S, P, l.shader, wl, child_slot, ray, depth, info, acc, q);
         }
     }
 }
@@ -709,6 +712,8 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
     }
 }
 
+#include "wavefront.h"
+
 // leaf_verts[ref] = tri_verts[leaf_tris[ref]] (9 doubles each): one pass at scene creation
 __global__ void gather_leaf_verts_kernel(const double* __restrict__ tri_verts, const uint32_t* __restrict__ leaf_tris,
                                          double* __restrict__ leaf_verts, size_t n_words) {
@@ -869,6 +874,7 @@ unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};     // device address of 
 int g_device = -1;
 int g_num_cu = 0;
 bool g_counting = false;
+int g_pipeline = 0;           // qd_set_pipeline: 0 = one persistent kernel with per-lane LIFO queues, 1 = wavefront pipeline (wavefront.h)
 int g_refine_leaf = 2;        // qd_set_kd_refine
 double g_refine_cost = 0.6;
 
@@ -892,6 +898,13 @@ struct WorkSet {
     size_t list_cap = 0;
     hipEvent_t idle = nullptr;               // recorded behind the set's last launch; a stream that takes the set over waits on it
     uint64_t last_use = 0;
+    // wavefront pipeline: ray queues of two alternating generations, hit records, control words, deep KD stack levels
+    uint64_t* wf_ray[2] = {nullptr, nullptr};
+    uint64_t* wf_hit = nullptr;
+    uint32_t* wf_ctl = nullptr;
+    uint2* wf_deep = nullptr;
+    size_t wf_cap = 0;
+    uint32_t wf_gens = 0;
 };
 
 // State of an AA pass between its three steps (mark / trace the taps / combine + resolve), see aa_begin.
@@ -944,6 +957,7 @@ void free_set(WorkSet& w) {
     if (w.stack) (void)hipFree(w.stack);
     if (w.queue_ctr) (void)hipFree(w.queue_ctr);
     for (int i = 0; i < 2; ++i) if (w.lists[i]) (void)hipFree(w.lists[i]);
+    for (void* p : {(void*)w.wf_ray[0], (void*)w.wf_ray[1], (void*)w.wf_hit, (void*)w.wf_ctl, (void*)w.wf_deep}) if (p) (void)hipFree(p);
     if (w.idle) (void)hipEventDestroy(w.idle);
     w = WorkSet();
 }
@@ -993,9 +1007,68 @@ int acquire_set(qd_scene* s, hipStream_t stream, uint32_t max_depth, WorkSet** o
 constexpr uint32_t kLaterPassDiv = QD_LATER_DIV;
 constexpr uint32_t kGrace = QD_GRACE;
 
+constexpr uint32_t kWfMaxGens = 66;          // generations a frame may have: maxTraceDepth + 2
+
+// The wavefront form of a frame (wavefront.h): trace(0) shade(0) trace(1) ... shade(D) trace(D + 1) on the stream.
+int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hipStream_t stream) {
+    if (max_depth + 2 > kWfMaxGens) return set_err("maxTraceDepth too large for the wavefront pipeline");
+    const uint64_t n_slots = (uint64_t)P.n_units * kUnitPx;
+    // queue capacity: a generation holds at most (rays of the one before) x (tasks queued per hit); generation 1 is bounded
+    // by pixels x spawn0, later ones shrink in every scene measured (rays leave the scene faster than glass doubles them):
+    // pixels x max(4, spawn0 + 1).  An overflow raises the scene's error flag (qd_scene_check), it never writes out of bounds.
+    uint64_t cap64 = n_slots * std::max<uint64_t>(4, (uint64_t)s->spawn0 + 1);
+    cap64 = std::max<uint64_t>(cap64, 1u << 16);
+    if (cap64 >= (1ull << 31)) return set_err("frame too large for the wavefront ray queues (split it into rectangles)");
+    if (!w->wf_ctl) HIP_TRY(hipMalloc((void**)&w->wf_ctl, (size_t)(kWfMaxGens + 1) * kWfGenWords * sizeof(uint32_t)));
+    if (!w->wf_deep) HIP_TRY(hipMalloc((void**)&w->wf_deep, (size_t)(kKdStack - kLdsStack) * s->n_lanes * sizeof(uint2)));
+    if (cap64 > w->wf_cap) {
+        for (void** p : {(void**)&w->wf_ray[0], (void**)&w->wf_ray[1], (void**)&w->wf_hit}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+        w->wf_cap = 0;
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipMalloc((void**)&w->wf_ray[i], (size_t)cap64 * kEntryWords * 8));
+        HIP_TRY(hipMalloc((void**)&w->wf_hit, (size_t)cap64 * kWfHitWords * 8));
+        w->wf_cap = (size_t)cap64;
+    }
+    P.wf_ray[0] = w->wf_ray[0]; P.wf_ray[1] = w->wf_ray[1]; P.wf_hit = w->wf_hit; P.wf_ctl = w->wf_ctl; P.wf_deep = w->wf_deep;
+    P.wf_cap = (uint32_t)w->wf_cap;
+    P.error_flag = s->error_flag;
+    HIP_TRY(hipMemsetAsync(w->wf_ctl, 0, (size_t)(max_depth + 3) * kWfGenWords * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));
+    using TraceK = void (*)(const DScene, const Params, int);
+#ifdef QD_DEV_BUILD      // quick compile for asm inspection: mask 0 and the copy with everything only
+    static const TraceK trace_k[8] = {wf_trace_kernel<false, 0>, wf_trace_kernel<false, 7>, wf_trace_kernel<false, 7>, wf_trace_kernel<false, 7>,
+                                      wf_trace_kernel<false, 7>, wf_trace_kernel<false, 7>, wf_trace_kernel<false, 7>, wf_trace_kernel<false, 7>};
+    static const TraceK shade_plain[8] = {wf_shade_kernel<0, false>, wf_shade_kernel<7, true>, wf_shade_kernel<7, true>, wf_shade_kernel<7, true>,
+                                          wf_shade_kernel<7, true>, wf_shade_kernel<7, true>, wf_shade_kernel<7, true>, wf_shade_kernel<7, true>};
+    static const TraceK shade_rich[8] = {wf_shade_kernel<7, true>, wf_shade_kernel<7, true>, wf_shade_kernel<7, true>, wf_shade_kernel<7, true>,
+                                         wf_shade_kernel<7, true>, wf_shade_kernel<7, true>, wf_shade_kernel<7, true>, wf_shade_kernel<7, true>};
+#else
+    static const TraceK trace_k[8] = {wf_trace_kernel<false, 0>, wf_trace_kernel<false, 1>, wf_trace_kernel<false, 2>, wf_trace_kernel<false, 3>,
+                                      wf_trace_kernel<false, 4>, wf_trace_kernel<false, 5>, wf_trace_kernel<false, 6>, wf_trace_kernel<false, 7>};
+    static const TraceK shade_plain[8] = {wf_shade_kernel<0, false>, wf_shade_kernel<1, false>, wf_shade_kernel<2, false>, wf_shade_kernel<3, false>,
+                                          wf_shade_kernel<4, false>, wf_shade_kernel<5, false>, wf_shade_kernel<6, false>, wf_shade_kernel<7, false>};
+    static const TraceK shade_rich[8] = {wf_shade_kernel<0, true>, wf_shade_kernel<1, true>, wf_shade_kernel<2, true>, wf_shade_kernel<3, true>,
+                                         wf_shade_kernel<4, true>, wf_shade_kernel<5, true>, wf_shade_kernel<6, true>, wf_shade_kernel<7, true>};
+#endif
+    const bool deep = (s->geom_mask & kGeomCsgDeep) != 0;
+    const TraceK tk = g_counting ? wf_trace_kernel<true, kGeomAll> : deep ? wf_trace_kernel<false, kGeomAll> : trace_k[s->geom_mask & 7];
+    const TraceK sk = (g_counting || deep) ? wf_shade_kernel<kGeomAll, true> : (s->rich ? shade_rich : shade_plain)[s->geom_mask & 7];
+    const uint32_t max_blocks = s->n_lanes / 64;
+    const uint32_t grid0 = (uint32_t)std::min<uint64_t>(max_blocks, std::max<uint64_t>(1, (n_slots + 63) / 64));
+    for (uint32_t g = 0; g <= max_depth + 1; ++g) {
+        hipLaunchKernelGGL(tk, dim3(grid0), dim3(64), 0, stream, s->d, P, (int)g);
+        HIP_TRY(hipGetLastError());
+        if (g == max_depth + 1) break;                                  // the last generation holds shadow rays only
+        hipLaunchKernelGGL(sk, dim3(grid0), dim3(64), 0, stream, s->d, P, (int)g);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(w->idle, stream));
+    return 0;
+}
+
 int launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream) {
     WorkSet* w = nullptr;
     if (acquire_set(s, stream, max_depth, &w)) return -1;
+    if (g_pipeline == 1) return launch_wavefront(s, w, P, max_depth, stream);
     P.stack = w->stack; P.stack_cap = w->stack_cap; P.n_lanes = s->n_lanes;
     P.error_flag = s->error_flag;
     P.list_cap = w->list_cap;
@@ -1013,10 +1086,17 @@ int launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream) {
         // later passes usually find an empty list; a launch costs ~45 ns per wave (scratch set-up), so they start fewer waves
         const uint32_t grid = pass == 0 ? (P.n_units < max_blocks ? (P.n_units ? P.n_units : 1) : max_blocks) : (max_blocks + kLaterPassDiv - 1) / kLaterPassDiv;
         using Kernel = void (*)(const DScene, const Params);
+#ifdef QD_DEV_BUILD
+        static const Kernel plain[8] = {trace_kernel<false, 0, false>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>,
+                                        trace_kernel<false, 7, true>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>};
+        static const Kernel rich[8] = {trace_kernel<false, 7, true>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>,
+                                       trace_kernel<false, 7, true>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>};
+#else
         static const Kernel plain[8] = {trace_kernel<false, 0, false>, trace_kernel<false, 1, false>, trace_kernel<false, 2, false>, trace_kernel<false, 3, false>,
                                         trace_kernel<false, 4, false>, trace_kernel<false, 5, false>, trace_kernel<false, 6, false>, trace_kernel<false, 7, false>};
         static const Kernel rich[8] = {trace_kernel<false, 0, true>, trace_kernel<false, 1, true>, trace_kernel<false, 2, true>, trace_kernel<false, 3, true>,
                                        trace_kernel<false, 4, true>, trace_kernel<false, 5, true>, trace_kernel<false, 6, true>, trace_kernel<false, 7, true>};
+#endif
         const Kernel kernel = g_counting ? trace_kernel<true, kGeomAll, true>                       // counting: one copy, all code
                             : (s->geom_mask & kGeomCsgDeep) ? trace_kernel<false, kGeomAll, true>    // CSG over CSG / mesh / heightfield: the copy with everything
                                          : (s->rich ? rich : plain)[s->geom_mask & 7];
@@ -1061,6 +1141,12 @@ extern "C" int qd_init(int device) {
 extern "C" void qd_shutdown(void) { g_device = -1; }
 
 extern "C" int qd_set_counting(int on) { g_counting = on != 0; return 0; }
+
+extern "C" int qd_set_pipeline(int pipeline) {
+    if (pipeline != 0 && pipeline != 1) return set_err("qd_set_pipeline: 0 (one kernel, per-lane queues) or 1 (wavefront)");
+    g_pipeline = pipeline;
+    return 0;
+}
 
 extern "C" int qd_set_kd_refine(int max_leaf_tris, double step_cost) {
     if (max_leaf_tris < 0 || !(step_cost > 0.)) return set_err("qd_set_kd_refine: max_leaf_tris >= 0 and step_cost > 0 required");

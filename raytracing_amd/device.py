@@ -45,6 +45,7 @@ def lib():
         L.qd_quantize_bgr8_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
         L.qd_pack_rgb32_async.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.qd_set_kd_refine.argtypes = [C.c_int, C.c_double]
+        L.qd_set_pipeline.argtypes = [C.c_int]
         L.qd_scene_kd_info.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
         L.qd_comm_unique_id.argtypes = [C.c_void_p]
         L.qd_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
@@ -81,6 +82,11 @@ def init(device=0):
 
 def set_counting(on):
     _check(lib().qd_set_counting(1 if on else 0), "qd_set_counting")
+
+
+def set_pipeline(pipeline):
+    """0 = one persistent kernel with per-lane ray queues, 1 = wavefront pipeline (generations of rays in HBM queues)."""
+    _check(lib().qd_set_pipeline(pipeline), "qd_set_pipeline")
 
 
 def set_kd_refine(max_leaf_tris=2, step_cost=0.6):

@@ -47,3 +47,13 @@ def synthetic_vertex_sha256(scene):
 def synthetic_sha():
     import json
     return json.load(open(os.path.join(ROOT, "tests", "golden", "synthetic_sha256.json")))
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _pipeline_from_env():
+    """QD_PIPELINE=0|1 runs the GPU suite on one scheduling form of the frame (qd_set_pipeline); unset = library default."""
+    v = os.environ.get("QD_PIPELINE")
+    if v is not None:
+        from raytracing_amd import device
+        device.set_pipeline(int(v))
+    yield
