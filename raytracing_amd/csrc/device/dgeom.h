@@ -37,6 +37,7 @@ struct DScene {
     const float* texels;
     const float* hf_f32;
     const double* hf_f64;
+    const int* node_kd_slot;      // per scene node: which walk launch of the wavefront pipeline answers it (KD-tree meshes), else -1
     int env_present, env_bilinear;
     int env_faces[6];
 };

@@ -84,7 +84,7 @@ struct Params {
     const uint64_t* in_list; const uint32_t* in_count;     // source 1: tasks, word-major (word w of task i at [w * list_cap + i]);
     uint64_t* out_list; uint32_t* out_count; size_t list_cap;   // eight regions of list_cap / 8 tasks with a count each
     // wavefront pipeline (wavefront.h): two ray queues (generations alternate), hit records, control words, deep KD stack levels
-    uint64_t* wf_ray[2]; uint64_t* wf_hit; uint32_t* wf_ctl; uint2* wf_deep; uint32_t wf_cap;
+    uint64_t* wf_ray[2]; uint64_t* wf_res; uint32_t* wf_ctl; uint2* wf_deep; uint32_t wf_cap;
 };
 
 struct Task {
@@ -242,9 +242,11 @@ __device__ QD_OUTLINE void eval_nested_layered(const DScene& S, const Params& P,
 // NESTED: a Layered shader met here (a layer that is itself Layered) goes to eval_nested_layered, which walks the inner
 // layers with an explicit stack and calls the NESTED = false copy for the leaves -- no recursion on the device.
 // Queue: where child rays go -- the lane's LIFO queue (one-kernel form) or the next generation's queue (wavefront form).
+// The body is inlined into the wavefront shading kernel (its own kernel, 2 waves per SIMD: +10 .. +30 % there) and sits
+// behind a real call in the one-kernel form (eval_leaf_shader below: the traversal's register allocation stays small).
 template <bool NESTED, bool RICH, class Queue>
-__device__ QD_OUTLINE void eval_leaf_shader(const DScene& S, const Params& P, int si, Col w, uint32_t slot, const Task& ray, uint32_t depth,
-                             const Info& info, Col& acc, Queue& q) {
+QD_DEV void eval_leaf_shader_body(const DScene& S, const Params& P, int si, Col w, uint32_t slot, const Task& ray, uint32_t depth,
+                                  const Info& info, Col& acc, Queue& q) {
     const qd_shader sh = S.shaders[si];
     switch (sh.type) {
         case QD_SH_LAYERED: if (NESTED) eval_nested_layered<RICH, Queue>(S, P, sh, w, slot, ray, depth, info, acc, q); break;
@@ -348,6 +350,12 @@ __device__ QD_OUTLINE void eval_leaf_shader(const DScene& S, const Params& P, in
         }
         default: break;
     }
+}
+
+template <bool NESTED, bool RICH, class Queue>
+__device__ QD_OUTLINE void eval_leaf_shader(const DScene& S, const Params& P, int si, Col w, uint32_t slot, const Task& ray, uint32_t depth,
+                             const Info& info, Col& acc, Queue& q) {
+    eval_leaf_shader_body<NESTED, RICH, Queue>(S, P, si, w, slot, ray, depth, info, acc, q);
 }
 
 // Layered::Shade (src/shading.cpp:260-275) for a Layered that is a layer of another one: the same suffix-product walk as
@@ -900,7 +908,7 @@ struct WorkSet {
     uint64_t last_use = 0;
     // wavefront pipeline: ray queues of two alternating generations, hit records, control words, deep KD stack levels
     uint64_t* wf_ray[2] = {nullptr, nullptr};
-    uint64_t* wf_hit = nullptr;
+    uint64_t* wf_res = nullptr;
     uint32_t* wf_ctl = nullptr;
     uint2* wf_deep = nullptr;
     size_t wf_cap = 0;
@@ -929,6 +937,7 @@ struct qd_scene {
     uint32_t spawn0 = 1, spawn1 = 1;     // tasks queued per hit at depth 0 / deeper
     int geom_mask = 7;                   // kGeomHf | kGeomCsg | kGeomPrim | kGeomCsgDeep as present in the scene: selects the kernel copy
     bool rich = true;                    // bitmap / Mandelbrot / procedural textures or bump maps present
+    std::vector<int> kd_node_list;       // scene nodes whose geometry is a mesh with a KD tree: one walk launch each (wavefront pipeline)
     uint64_t kd_nodes = 0, kd_refs = 0, kd_leaves = 0, kd_max_leaf = 0;   // device tree after refinement
 };
 
@@ -957,7 +966,7 @@ void free_set(WorkSet& w) {
     if (w.stack) (void)hipFree(w.stack);
     if (w.queue_ctr) (void)hipFree(w.queue_ctr);
     for (int i = 0; i < 2; ++i) if (w.lists[i]) (void)hipFree(w.lists[i]);
-    for (void* p : {(void*)w.wf_ray[0], (void*)w.wf_ray[1], (void*)w.wf_hit, (void*)w.wf_ctl, (void*)w.wf_deep}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)w.wf_ray[0], (void*)w.wf_ray[1], (void*)w.wf_res, (void*)w.wf_ctl, (void*)w.wf_deep}) if (p) (void)hipFree(p);
     if (w.idle) (void)hipEventDestroy(w.idle);
     w = WorkSet();
 }
@@ -1007,57 +1016,60 @@ int acquire_set(qd_scene* s, hipStream_t stream, uint32_t max_depth, WorkSet** o
 constexpr uint32_t kLaterPassDiv = QD_LATER_DIV;
 constexpr uint32_t kGrace = QD_GRACE;
 
-constexpr uint32_t kWfMaxGens = 66;          // generations a frame may have: maxTraceDepth + 2
+constexpr uint32_t kWfMaxGens = 67;          // generations a frame may have: maxTraceDepth + 2
 
-// The wavefront form of a frame (wavefront.h): trace(0) shade(0) trace(1) ... shade(D) trace(D + 1) on the stream.
+// The wavefront form of a frame (wavefront.h): walk(0) shade(0) walk(1) ... walk(D + 1) shade(D + 1) on the stream.
 int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hipStream_t stream) {
-    if (max_depth + 2 > kWfMaxGens) return set_err("maxTraceDepth too large for the wavefront pipeline");
+    if (max_depth + 3 > kWfMaxGens) return set_err("maxTraceDepth too large for the wavefront pipeline");
     const uint64_t n_slots = (uint64_t)P.n_units * kUnitPx;
     // queue capacity: a generation holds at most (rays of the one before) x (tasks queued per hit); generation 1 is bounded
     // by pixels x spawn0, later ones shrink in every scene measured (rays leave the scene faster than glass doubles them):
-    // pixels x max(4, spawn0 + 1).  An overflow raises the scene's error flag (qd_scene_check), it never writes out of bounds.
+    // pixels x max(4, spawn0 + 1).  An overflow raises the scene's error flag, it never writes out of bounds: the synchronous
+    // entry points then render the call again in the one-kernel form (whose queues are bounded by construction), the
+    // asynchronous ones report it through qd_scene_check.
     uint64_t cap64 = n_slots * std::max<uint64_t>(4, (uint64_t)s->spawn0 + 1);
+    // small launches (a bucket, a rectangle that lies on glass) get up to 32 entries per pixel while that stays below 8 M entries
+    cap64 = std::max<uint64_t>(cap64, std::min<uint64_t>(n_slots * 32, 8u << 20));
     cap64 = std::max<uint64_t>(cap64, 1u << 16);
     if (cap64 >= (1ull << 31)) return set_err("frame too large for the wavefront ray queues (split it into rectangles)");
+    const size_t n_kd = std::max<size_t>(1, s->kd_node_list.size());
     if (!w->wf_ctl) HIP_TRY(hipMalloc((void**)&w->wf_ctl, (size_t)(kWfMaxGens + 1) * kWfGenWords * sizeof(uint32_t)));
     if (!w->wf_deep) HIP_TRY(hipMalloc((void**)&w->wf_deep, (size_t)(kKdStack - kLdsStack) * s->n_lanes * sizeof(uint2)));
     if (cap64 > w->wf_cap) {
-        for (void** p : {(void**)&w->wf_ray[0], (void**)&w->wf_ray[1], (void**)&w->wf_hit}) if (*p) { (void)hipFree(*p); *p = nullptr; }
+        for (void** p : {(void**)&w->wf_ray[0], (void**)&w->wf_ray[1], (void**)&w->wf_res}) if (*p) { (void)hipFree(*p); *p = nullptr; }
         w->wf_cap = 0;
         for (int i = 0; i < 2; ++i) HIP_TRY(hipMalloc((void**)&w->wf_ray[i], (size_t)cap64 * kEntryWords * 8));
-        HIP_TRY(hipMalloc((void**)&w->wf_hit, (size_t)cap64 * kWfHitWords * 8));
+        HIP_TRY(hipMalloc((void**)&w->wf_res, (size_t)cap64 * kWfResWords * 8 * n_kd));
         w->wf_cap = (size_t)cap64;
     }
-    P.wf_ray[0] = w->wf_ray[0]; P.wf_ray[1] = w->wf_ray[1]; P.wf_hit = w->wf_hit; P.wf_ctl = w->wf_ctl; P.wf_deep = w->wf_deep;
+    P.wf_ray[0] = w->wf_ray[0]; P.wf_ray[1] = w->wf_ray[1]; P.wf_res = w->wf_res; P.wf_ctl = w->wf_ctl; P.wf_deep = w->wf_deep;
     P.wf_cap = (uint32_t)w->wf_cap;
     P.error_flag = s->error_flag;
     HIP_TRY(hipMemsetAsync(w->wf_ctl, 0, (size_t)(max_depth + 3) * kWfGenWords * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));
-    using TraceK = void (*)(const DScene, const Params, int);
-#ifdef QD_DEV_BUILD      // quick compile for asm inspection: mask 0 and the copy with everything only
-    static const TraceK trace_k[8] = {wf_trace_kernel<false, 0>, wf_trace_kernel<false, 7>, wf_trace_kernel<false, 7>, wf_trace_kernel<false, 7>,
-                                      wf_trace_kernel<false, 7>, wf_trace_kernel<false, 7>, wf_trace_kernel<false, 7>, wf_trace_kernel<false, 7>};
-    static const TraceK shade_plain[8] = {wf_shade_kernel<0, false>, wf_shade_kernel<7, true>, wf_shade_kernel<7, true>, wf_shade_kernel<7, true>,
-                                          wf_shade_kernel<7, true>, wf_shade_kernel<7, true>, wf_shade_kernel<7, true>, wf_shade_kernel<7, true>};
-    static const TraceK shade_rich[8] = {wf_shade_kernel<7, true>, wf_shade_kernel<7, true>, wf_shade_kernel<7, true>, wf_shade_kernel<7, true>,
-                                         wf_shade_kernel<7, true>, wf_shade_kernel<7, true>, wf_shade_kernel<7, true>, wf_shade_kernel<7, true>};
+    using ShadeK = void (*)(const DScene, const Params, int);
+#ifdef QD_DEV_BUILD      // quick compile for development: mask 0 and the copy with everything only
+    static const ShadeK shade_plain[8] = {wf_shade_kernel<false, 0, false>, wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>,
+                                          wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>};
+    static const ShadeK shade_rich[8] = {wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>,
+                                         wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>};
 #else
-    static const TraceK trace_k[8] = {wf_trace_kernel<false, 0>, wf_trace_kernel<false, 1>, wf_trace_kernel<false, 2>, wf_trace_kernel<false, 3>,
-                                      wf_trace_kernel<false, 4>, wf_trace_kernel<false, 5>, wf_trace_kernel<false, 6>, wf_trace_kernel<false, 7>};
-    static const TraceK shade_plain[8] = {wf_shade_kernel<0, false>, wf_shade_kernel<1, false>, wf_shade_kernel<2, false>, wf_shade_kernel<3, false>,
-                                          wf_shade_kernel<4, false>, wf_shade_kernel<5, false>, wf_shade_kernel<6, false>, wf_shade_kernel<7, false>};
-    static const TraceK shade_rich[8] = {wf_shade_kernel<0, true>, wf_shade_kernel<1, true>, wf_shade_kernel<2, true>, wf_shade_kernel<3, true>,
-                                         wf_shade_kernel<4, true>, wf_shade_kernel<5, true>, wf_shade_kernel<6, true>, wf_shade_kernel<7, true>};
+    static const ShadeK shade_plain[8] = {wf_shade_kernel<false, 0, false>, wf_shade_kernel<false, 1, false>, wf_shade_kernel<false, 2, false>, wf_shade_kernel<false, 3, false>,
+                                          wf_shade_kernel<false, 4, false>, wf_shade_kernel<false, 5, false>, wf_shade_kernel<false, 6, false>, wf_shade_kernel<false, 7, false>};
+    static const ShadeK shade_rich[8] = {wf_shade_kernel<false, 0, true>, wf_shade_kernel<false, 1, true>, wf_shade_kernel<false, 2, true>, wf_shade_kernel<false, 3, true>,
+                                         wf_shade_kernel<false, 4, true>, wf_shade_kernel<false, 5, true>, wf_shade_kernel<false, 6, true>, wf_shade_kernel<false, 7, true>};
 #endif
     const bool deep = (s->geom_mask & kGeomCsgDeep) != 0;
-    const TraceK tk = g_counting ? wf_trace_kernel<true, kGeomAll> : deep ? wf_trace_kernel<false, kGeomAll> : trace_k[s->geom_mask & 7];
-    const TraceK sk = (g_counting || deep) ? wf_shade_kernel<kGeomAll, true> : (s->rich ? shade_rich : shade_plain)[s->geom_mask & 7];
+    const ShadeK sk = g_counting ? wf_shade_kernel<true, kGeomAll, true> : deep ? wf_shade_kernel<false, kGeomAll, true>
+                                 : (s->rich ? shade_rich : shade_plain)[s->geom_mask & 7];
     const uint32_t max_blocks = s->n_lanes / 64;
     const uint32_t grid0 = (uint32_t)std::min<uint64_t>(max_blocks, std::max<uint64_t>(1, (n_slots + 63) / 64));
     for (uint32_t g = 0; g <= max_depth + 1; ++g) {
-        hipLaunchKernelGGL(tk, dim3(grid0), dim3(64), 0, stream, s->d, P, (int)g);
-        HIP_TRY(hipGetLastError());
-        if (g == max_depth + 1) break;                                  // the last generation holds shadow rays only
+        for (size_t k = 0; k < s->kd_node_list.size(); ++k) {
+            if (g_counting) hipLaunchKernelGGL(wf_walk_kernel<true>, dim3(grid0), dim3(64), 0, stream, s->d, P, (int)g, s->kd_node_list[k], (int)k);
+            else hipLaunchKernelGGL(wf_walk_kernel<false>, dim3(grid0), dim3(64), 0, stream, s->d, P, (int)g, s->kd_node_list[k], (int)k);
+            HIP_TRY(hipGetLastError());
+        }
         hipLaunchKernelGGL(sk, dim3(grid0), dim3(64), 0, stream, s->d, P, (int)g);
         HIP_TRY(hipGetLastError());
     }
@@ -1068,7 +1080,7 @@ int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hip
 int launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream) {
     WorkSet* w = nullptr;
     if (acquire_set(s, stream, max_depth, &w)) return -1;
-    if (g_pipeline == 1) return launch_wavefront(s, w, P, max_depth, stream);
+    if (g_pipeline == 1 && s->kd_node_list.size() <= kWfMaxKdNodes) return launch_wavefront(s, w, P, max_depth, stream);
     P.stack = w->stack; P.stack_cap = w->stack_cap; P.n_lanes = s->n_lanes;
     P.error_flag = s->error_flag;
     P.list_cap = w->list_cap;
@@ -1331,6 +1343,14 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
             }
         }
     }
+    {
+        std::vector<int> slot(desc->n_nodes, -1);
+        for (uint32_t i = 0; i < desc->n_nodes; ++i) {
+            const qd_geom& g = desc->geoms[desc->nodes[i].geom];
+            if (g.type == QD_GEOM_MESH && meshes_dev[g.a].kd_root >= 0) { slot[i] = (int)s->kd_node_list.size(); s->kd_node_list.push_back((int)i); }
+        }
+        rc |= upload(s, slot.data(), slot.size(), &d.node_kd_slot);
+    }
     rc |= upload(s, desc->texels, (size_t)desc->n_texels * 3, &d.texels);
     rc |= upload(s, desc->hf_f32, (size_t)desc->n_hf_f32, &d.hf_f32);
     rc |= upload(s, desc->hf_f64, (size_t)desc->n_hf_f64, &d.hf_f64);
@@ -1423,6 +1443,20 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
     float ms = 0; TRY2(hipEventElapsedTime(&ms, e0, e1));
     int err_flag = 0;
     TRY2(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (err_flag && g_pipeline == 1) {
+        // a generation outgrew the wavefront queues (a rectangle full of glass): the same call in the one-kernel form
+        TRY2(hipMemsetAsync(s->stats, 0, 24 * sizeof(unsigned long long), nullptr));
+        TRY2(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
+        TRY2(hipEventRecord(e0, nullptr));
+        g_pipeline = 0;
+        rc = launch(s, P, st->max_trace_depth, nullptr);
+        g_pipeline = 1;
+        if (rc) { cleanup(); return -1; }
+        TRY2(hipEventRecord(e1, nullptr));
+        TRY2(hipEventSynchronize(e1));
+        TRY2(hipEventElapsedTime(&ms, e0, e1));
+        TRY2(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
+    }
     if (err_flag) { cleanup(); return set_err("qd_render: ray queue overflow on device"); }
     if (pitch == (size_t)rw * 3) TRY2(hipMemcpy(rgb, d_rgb, npx * 3 * sizeof(float), hipMemcpyDeviceToHost));      // contiguous rows: one copy
     else TRY2(hipMemcpy2D(rgb, pitch * sizeof(float), d_rgb, (size_t)rw * 3 * sizeof(float), (size_t)rw * 3 * sizeof(float), rh, hipMemcpyDeviceToHost));
@@ -1597,6 +1631,19 @@ int antialias_impl(qd_scene* s, const qd_camera* cam, const qd_settings* st, flo
         TRY2(hipEventRecord(e1, nullptr));
         TRY2(hipEventSynchronize(e1));
         TRY2(hipEventElapsedTime(&ms, e0, e1));
+        if (g_pipeline == 1) {                  // taps that outgrew the wavefront queues: once more in the one-kernel form
+            int err_flag = 0;
+            TRY2(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
+            if (err_flag == 1) {
+                TRY2(hipMemsetAsync(s->stats, 0, 16 * sizeof(unsigned long long), nullptr));
+                TRY2(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
+                g_pipeline = 0;
+                const int rc2 = aa_trace(s, cam, st, 0, n_list, d_taps, s->stats, nullptr);
+                g_pipeline = 1;
+                if (rc2) { cleanup(); return -1; }
+                TRY2(hipDeviceSynchronize());
+            }
+        }
     }
     if (aa_end(s, st, d_taps, frame)) { cleanup(); return -1; }
     if (!rgb_dev) TRY2(hipMemcpy2D(rgb, pitch * sizeof(float), frame, (size_t)W * 3 * sizeof(float), (size_t)W * 3 * sizeof(float), H, hipMemcpyDeviceToHost));

@@ -9,7 +9,7 @@ cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fP
        "-DQD_DEV_BUILD", "-I", os.path.join(ROOT, "include"), "-I", os.path.dirname(src), "-S", "--cuda-device-only", src, "-o", out] + sys.argv[1:]
 subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 lines = open(out).read().split("\n")
-names = [l.split(":")[0] for l in lines if re.match(r"^_ZN12_GLOBAL__N_1\d+(wf_trace_kernelILb0ELi0E|wf_shade_kernelILi0ELb0E|trace_kernelILb0ELi0ELb0E)", l)]
+names = [l.split(":")[0] for l in lines if re.match(r"^_ZN12_GLOBAL__N_1\d+(wf_walk_kernelILb0E|wf_shade_kernelILb0ELi0ELb0E|trace_kernelILb0ELi0ELb0E)", l)]
 for name in names:
     start = next(i for i, l in enumerate(lines) if l.startswith(name + ":"))
     end = next(i for i in range(start + 10, len(lines)) if lines[i].startswith(".Lfunc_end"))

@@ -12,9 +12,9 @@ rows = list(csv.DictReader(open(sys.argv[1] + "/kernel_trace.csv")))
 rows = [r for r in rows if "wf_" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last frame: find the last trace kernel whose predecessor gap is large ... simply print the last 2*D+3 launches
-n = 19
+n = 20
 t0 = int(rows[-n]["Start_Timestamp"])
 for r in rows[-n:]:
-    print(("trace" if "wf_trace" in r["Kernel_Name"] else "shade"), "start %8.3f ms  dur %8.3f ms" % ((int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+    print(("walk " if "wf_walk" in r["Kernel_Name"] else "shade"), "start %8.3f ms  dur %8.3f ms" % ((int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
 PY
 rm -rf "$OUT/ktrace"

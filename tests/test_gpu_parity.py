@@ -493,8 +493,9 @@ def test_specialised_kernel_copy_equals_the_all_code_copy(load_scene, data_dir, 
         if old is not None:
             _aa_settings(s, **old)
     assert np.array_equal(hn0, hn1) and np.array_equal(ht0, ht1) and np.array_equal(hd0.view(np.uint64), hd1.view(np.uint64))
-    # float additions land in a different order in the two runs; a glossy pixel sums 25+ samples of magnitude > 1
-    assert np.abs(rgb0 - rgb1).max() <= 5 * SUM_ORDER_TOL
+    # float additions land in a different order in the two runs; a glossy pixel sums 25+ samples of magnitude > 1, so the
+    # rounding of the sum scales with the pixel's value
+    assert (np.abs(rgb0 - rgb1) <= 5 * SUM_ORDER_TOL * np.maximum(1.0, np.abs(rgb1))).all(), float(np.abs(rgb0 - rgb1).max())
     assert st0["rays"] == st1["rays"] and st0["shadow_rays"] == st1["shadow_rays"]
 
 
