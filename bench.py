@@ -98,6 +98,7 @@ def main():
                     help="frames enqueued at a time, one HIP stream each (1 = strictly one after the other; 0 = by shard size: 2 at 1 GPU, 3 at 2, 4 at 4, 6 beyond)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", type=int, default=None, help="qd_set_pipeline: 0 = one kernel with per-lane queues, 1 = wavefront (default = library default)")
+    ap.add_argument("--kd-build", type=int, default=None, help="qd_set_kd_build: 1 = device tree by SAH from the triangles, 0 = the caller's planes + refined leaves")
     ap.add_argument("--kd-refine", default=None, help="'max_leaf,step_cost' for qd_set_kd_refine (tuning; default = library default)")
     args = ap.parse_args()
     args.width_set = args.width is not None
@@ -125,6 +126,8 @@ def main():
         args.frames_in_flight = 2 if world == 1 else 3 if world == 2 else 4 if world <= 4 else 6
     if args.pipeline is not None:
         device.set_pipeline(args.pipeline)
+    if args.kd_build is not None:
+        device.set_kd_build(args.kd_build)
     if args.kd_refine:
         ml, sc = args.kd_refine.split(",")
         device.set_kd_refine(int(ml), float(sc))

@@ -35,6 +35,8 @@ struct Options {
     int max_leaf = 2;          // leaves with at most this many triangles are never split; 0 = keep the caller's leaves
     double cost_step = 0.6;    // cost of one descent step, in triangle tests
     int max_depth = 70;        // below the device traversal stack (kKdStack)
+    bool rebuild = false;      // true: ignore the caller's planes, build the whole tree with the surface-area heuristic
+    uint32_t binned_above = 192;   // nodes with more triangles choose their plane from 64 bins per axis, smaller ones by an exact sweep
 };
 
 inline double half_area(const Box& b) {
@@ -66,6 +68,43 @@ struct SubTree {
     std::vector<uint32_t> refs;        // mesh-local triangle indices
 };
 
+// Plane of a node with many triangles: 64 bins per axis over the clipped triangle bounds (every `stride`-th triangle is
+// binned: a sample is enough for the histograms of a node with millions of triangles).  The candidates are the 63 bin
+// boundaries per axis; the counts left / right of a boundary are what the exact classification (goes_left / goes_right)
+// would give up to the triangles that end exactly on it.
+inline void binned_plane(const Box& box, const TriBounds* tb, uint32_t n, uint32_t stride, const Options& opt,
+                         double& best_cost, int& best_axis, double& best_split) {
+    constexpr int K = 64;
+    const double area = half_area(box);
+    const double scale = (double)stride;
+    for (int a = 0; a < 3; ++a) {
+        const double L = box.lo[a], W = box.hi[a] - box.lo[a];
+        if (!(W > 0.)) continue;
+        uint32_t starts[K] = {0}, ends[K] = {0};
+        const double inv = K / W;
+        for (uint32_t i = 0; i < n; i += stride) {
+            int b0 = (int)((tb[i].lo[a] - L) * inv), b1 = (int)((tb[i].hi[a] - L) * inv);
+            b0 = std::min(std::max(b0, 0), K - 1); b1 = std::min(std::max(b1, 0), K - 1);
+            starts[b0]++; ends[b1]++;
+        }
+        const int u = (a + 1) % 3, v = (a + 2) % 3;
+        const double du = box.hi[u] - box.lo[u], dv = box.hi[v] - box.lo[v];
+        uint32_t below = 0, total = 0;
+        for (int b = 0; b < K; ++b) total += ends[b];
+        uint32_t ended = 0;
+        for (int b = 1; b < K; ++b) {
+            below += starts[b - 1]; ended += ends[b - 1];
+            const double s = L + W * ((double)b / K);
+            const double nl = below * scale, nr = (total - ended) * scale;          // starts before the boundary; ends in a bin at or after it
+            const double dl = s - box.lo[a], dr = box.hi[a] - s;
+            const double al = du * dv + (du + dv) * dl, ar = du * dv + (du + dv) * dr;
+            double cost = opt.cost_step + (al * nl + ar * nr) / area;
+            if (below == 0 || total == ended) cost *= 0.8;                           // cutting off empty space
+            if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = s; }
+        }
+    }
+}
+
 class Builder {
 public:
     Builder(const double* tri_verts, uint32_t tri_first, const Options& opt) : tv_(tri_verts), first_(tri_first), opt_(opt) {}
@@ -95,8 +134,9 @@ private:
         double best_cost = (double)n;          // cost of staying a leaf
         int best_axis = -1;
         double best_split = 0.;
-        std::vector<double> los(n), his(n), flat, cand;
-        for (int a = 0; a < 3; ++a) {
+        if (n > opt_.binned_above) binned_plane(box, tb.data(), n, 1, opt_, best_cost, best_axis, best_split);
+        std::vector<double> los(n > opt_.binned_above ? 0 : n), his(los.size()), flat, cand;
+        for (int a = 0; a < 3 && n <= opt_.binned_above; ++a) {
             if (!(box.hi[a] > box.lo[a])) continue;
             flat.clear(); cand.clear();
             for (uint32_t i = 0; i < n; ++i) {
@@ -162,7 +202,53 @@ inline std::string refine(const qd_scene_desc* d, const Options& opt, Result& R)
         // 1. the caller's inner nodes, copied; one job per leaf
         struct Job { size_t at; Box box; std::vector<uint32_t> tris; int depth; };
         std::vector<Job> jobs;
-        {
+        if (opt.rebuild) {
+            // whole tree by the surface-area heuristic: the top of the tree is split here, one node after the other (planes from
+            // binned, sampled bounds; the classification of every triangle is exact), until a node holds few enough triangles
+            // to be one of the parallel jobs below
+            const uint32_t job_tris = 32768;
+            Box root;
+            for (int a = 0; a < 3; ++a) { root.lo[a] = m.bbox_min[a]; root.hi[a] = m.bbox_max[a]; }
+            T.nodes.push_back(BNode{0., 0u, 0u, 3});
+            std::vector<uint32_t> all(m.tri_count);
+            for (uint32_t i = 0; i < m.tri_count; ++i) all[i] = i;
+            std::vector<Job> todo;
+            todo.push_back(Job{0, root, std::move(all), 0});
+            std::vector<TriBounds> tb;
+            while (!todo.empty()) {
+                Job j = std::move(todo.back()); todo.pop_back();
+                const uint32_t n = (uint32_t)j.tris.size();
+                if (n <= job_tris || j.depth >= opt.max_depth - 24) { jobs.push_back(std::move(j)); continue; }
+                const uint32_t stride = std::max(1u, n / 262144u);
+                tb.resize((n + stride - 1) / stride);
+                for (uint32_t i = 0, k = 0; i < n; i += stride, ++k) tb[k] = tri_bounds(d->tri_verts, m.tri_first + j.tris[i], j.box);
+                double best_cost = (double)n; int axis = -1; double split = 0.;
+                binned_plane(j.box, tb.data(), (uint32_t)tb.size(), 1, opt, best_cost, axis, split);
+                if (axis >= 0) best_cost = 0;       // histogram counts were those of the sample: any plane found beats a leaf of this size
+                if (axis < 0) { jobs.push_back(std::move(j)); continue; }
+                std::vector<uint32_t> left, right;
+                left.reserve(n / 2 + n / 8); right.reserve(n / 2 + n / 8);
+                for (uint32_t i = 0; i < n; ++i) {
+                    const double* v = d->tri_verts + (size_t)(m.tri_first + j.tris[i]) * 9;
+                    const double p0 = v[axis], p1 = v[axis] + v[3 + axis], p2 = v[axis] + v[6 + axis];
+                    double lo = std::max(std::min(p0, std::min(p1, p2)), j.box.lo[axis]);
+                    double hi = std::min(std::max(p0, std::max(p1, p2)), j.box.hi[axis]);
+                    if (hi < lo) hi = lo;
+                    if (goes_left(lo, hi, split)) left.push_back(j.tris[i]);
+                    if (goes_right(hi, split)) right.push_back(j.tris[i]);
+                }
+                if (left.size() == n && right.size() == n) { jobs.push_back(std::move(j)); continue; }
+                const size_t c = T.nodes.size();
+                T.nodes.push_back(BNode{0., 0u, 0u, 3});
+                T.nodes.push_back(BNode{0., 0u, 0u, 3});
+                T.nodes[j.at] = BNode{split, (uint32_t)c, 0u, (uint8_t)axis};
+                Box bl = j.box, br = j.box;
+                bl.hi[axis] = split; br.lo[axis] = split;
+                std::vector<uint32_t>().swap(j.tris);
+                todo.push_back(Job{c + 1, br, std::move(right), j.depth + 1});
+                todo.push_back(Job{c, bl, std::move(left), j.depth + 1});
+            }
+        } else {
             struct Item { uint32_t src; size_t dst; Box box; int depth; };
             std::vector<Item> stack;
             Box root;
@@ -192,12 +278,14 @@ inline std::string refine(const qd_scene_desc* d, const Options& opt, Result& R)
         std::vector<SubTree> subs(jobs.size());
         unsigned n_thr = std::thread::hardware_concurrency();
         n_thr = std::max(1u, std::min(n_thr, 16u));
-        if (jobs.size() < 4096) n_thr = 1;
+        if (jobs.size() < 4096 && !opt.rebuild) n_thr = 1;
+        if (opt.rebuild && m.tri_count < 20000) n_thr = 1;
+        const size_t grain = opt.rebuild ? 1 : 256;
         std::atomic<size_t> next{0};
         auto worker = [&]() {
             Builder bld(d->tri_verts, m.tri_first, opt);
             for (;;) {
-                const size_t b = next.fetch_add(256), e = std::min(jobs.size(), b + 256);
+                const size_t b = next.fetch_add(grain), e = std::min(jobs.size(), b + grain);
                 if (b >= jobs.size()) break;
                 for (size_t j = b; j < e; ++j) bld.build(subs[j], jobs[j].box, jobs[j].tris, jobs[j].depth);
             }

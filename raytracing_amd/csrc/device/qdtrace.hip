@@ -885,6 +885,7 @@ bool g_counting = false;
 int g_pipeline = 0;           // qd_set_pipeline: 0 = one persistent kernel with per-lane LIFO queues, 1 = wavefront pipeline (wavefront.h)
 int g_refine_leaf = 2;        // qd_set_kd_refine
 double g_refine_cost = 0.6;
+int g_kd_build = 1;           // qd_set_kd_build: 0 = the caller's planes, leaves refined; 1 = whole tree by the surface-area heuristic
 
 int set_err(const std::string& m) { g_err = m; return -1; }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
@@ -1154,6 +1155,12 @@ extern "C" void qd_shutdown(void) { g_device = -1; }
 
 extern "C" int qd_set_counting(int on) { g_counting = on != 0; return 0; }
 
+extern "C" int qd_set_kd_build(int mode) {
+    if (mode != 0 && mode != 1) return set_err("qd_set_kd_build: 0 (the caller's planes, leaves refined) or 1 (whole tree by the surface-area heuristic)");
+    g_kd_build = mode;
+    return 0;
+}
+
 extern "C" int qd_set_pipeline(int pipeline) {
     if (pipeline != 0 && pipeline != 1) return set_err("qd_set_pipeline: 0 (one kernel, per-lane queues) or 1 (wavefront)");
     g_pipeline = pipeline;
@@ -1302,6 +1309,7 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
         opt.max_leaf = g_refine_leaf;
         opt.cost_step = g_refine_cost;
         opt.max_depth = kKdStack - 2;
+        opt.rebuild = g_kd_build == 1 && g_refine_leaf > 0;
         qd_refine::Result refined;
         const std::string err = qd_refine::refine(desc, opt, refined);
         if (!err.empty()) { delete s; return set_err("qd_scene_create: " + err); }

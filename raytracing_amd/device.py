@@ -46,6 +46,7 @@ def lib():
         L.qd_pack_rgb32_async.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.qd_set_kd_refine.argtypes = [C.c_int, C.c_double]
         L.qd_set_pipeline.argtypes = [C.c_int]
+        L.qd_set_kd_build.argtypes = [C.c_int]
         L.qd_scene_kd_info.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
         L.qd_comm_unique_id.argtypes = [C.c_void_p]
         L.qd_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
@@ -82,6 +83,11 @@ def init(device=0):
 
 def set_counting(on):
     _check(lib().qd_set_counting(1 if on else 0), "qd_set_counting")
+
+
+def set_kd_build(mode):
+    """Device KD tree of scenes created afterwards: 1 = whole tree by the surface-area heuristic, 0 = the caller's planes with refined leaves."""
+    _check(lib().qd_set_kd_build(mode), "qd_set_kd_build")
 
 
 def set_pipeline(pipeline):

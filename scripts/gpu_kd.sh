@@ -1,0 +1,17 @@
+#!/bin/bash
+# device tree build modes x pipelines on the bench scene and kdtree_fixed.  usage: scripts/gpu_kd.sh <tag>
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/$1; mkdir -p "$OUT"
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > "$OUT/pytest_gpu.log" 2>&1; rc=$?
+tail -3 "$OUT/pytest_gpu.log"; [ $rc -ne 0 ] && exit $rc
+for wl in "" "--workload kdtree_fixed.qdmg" "--workload hw9/dragon.qdmg --width 3840 --height 2160"; do
+ for kb in 0 1; do
+  for p in 0 1; do
+    for f in 1 2; do
+      timeout -k 10 300 python -u bench.py --kd-build $kb --pipeline $p --frames-in-flight $f --steps 8 --warmup 2 --no-cpu-baseline $wl > "$OUT/b.json" 2> "$OUT/b.err" || { tail -5 "$OUT/b.err"; exit 1; }
+      python3 -c "import json,sys; d=json.loads(open('$OUT/b.json').read().strip().splitlines()[-1]); r=d['roofline']; print('$wl | kd-build $kb pipeline $p F $f:', round(d['value']/1e6,1),'Mrays/s', round(d['ms_per_step'],2),'ms/frame', round(r['kernel_ms'],2),'ms lone', 'visits', r['kd_nodes_visited'], 'tris', r['tris_tested'])"
+    done
+  done
+ done
+done

@@ -1,6 +1,8 @@
 // CPU check of the device KD construction (raytracing_amd/csrc/device/kdrefine.h): builds the records for a scene and
 // walks them on the host with the same rules as the kernel's mesh_query, against a brute-force closest hit.
-// usage: kdrefine_check <scene.qdmg> <rays> <max_leaf> <step_cost>     prints "rays R mismatches M ..."
+// usage: kdrefine_check <scene.qdmg | synth:N> <rays> <max_leaf> <step_cost> [rebuild 0|1] [brute 1|0] [cam 0|1]
+//        prints "rays R mismatches M ..."; synth:N = the synthetic bench mesh with 2*N*N triangles; brute 0 skips the brute-force
+//        check (tree statistics only); cam 1 shoots the rays from the bench camera's position instead of from around the box
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -33,10 +35,11 @@ static bool tri_test(const double* t, V o, V d, double& best) {
 
 int main(int argc, char** argv) {
     if (argc < 5) return 2;
-    qdh_scene* hs = qdh_load_scene(argv[1]);
+    qdh_scene* hs = std::strncmp(argv[1], "synth:", 6) == 0 ? qdh_synth_scene(std::atoi(argv[1] + 6), 42, 640, 360, 8, nullptr) : qdh_load_scene(argv[1]);
+    const bool rebuild = argc > 5 && std::atoi(argv[5]) != 0, do_brute = !(argc > 6 && std::atoi(argv[6]) == 0), cam = argc > 7 && std::atoi(argv[7]) != 0;
     if (!hs) { std::printf("load failed: %s\n", qdh_last_error()); return 2; }
     const qd_scene_desc* d = qdh_scene_desc(hs);
-    qd_refine::Options opt; opt.max_leaf = std::atoi(argv[3]); opt.cost_step = std::atof(argv[4]);
+    qd_refine::Options opt; opt.max_leaf = std::atoi(argv[3]); opt.cost_step = std::atof(argv[4]); opt.rebuild = rebuild;
     qd_refine::Result R;
     const std::string err = qd_refine::refine(d, opt, R);
     if (!err.empty()) { std::printf("refine failed: %s\n", err.c_str()); return 2; }
@@ -64,13 +67,14 @@ int main(int argc, char** argv) {
                 const double* t = tv + (size_t)(rng() % m.tri_count) * 9;
                 o.x = t[0];
             }
+            if (cam) o = V{0.073, 0.7, -1.4};             // the bench camera in the mesh's object space (node scale 100)
             V p{lo.x + ext.x * U(rng), lo.y + ext.y * U(rng), lo.z + ext.z * U(rng)};
             V dd = sub(p, o);
             const double len = std::sqrt(dot(dd, dd));
             const V dir{dd.x * (1. / len), dd.y * (1. / len), dd.z * (1. / len)};
             if (r % 7 == 0) { const_cast<double&>(dir.y) = 0.; }
             double brute = 1e99;
-            for (uint32_t t = 0; t < m.tri_count; ++t) tri_test(tv + (size_t)t * 9, o, dir, brute);
+            if (do_brute) for (uint32_t t = 0; t < m.tri_count; ++t) tri_test(tv + (size_t)t * 9, o, dir, brute);
             // ---- the kernel's walk (dgeom.h mesh_query) on the host
             double t0 = 0., t1 = 1e99, best = 1e99;
             const double oc[3] = {o.x, o.y, o.z}, dc[3] = {dir.x, dir.y, dir.z};
@@ -123,7 +127,7 @@ int main(int argc, char** argv) {
                 }
             }
             if (brute < 1e98) ++hits;
-            if (best != brute) { if (++mismatches <= 5) std::printf("ray %d: walk %.17g brute %.17g\n", r, best, brute); }
+            if (do_brute && best != brute) { if (++mismatches <= 5) std::printf("ray %d: walk %.17g brute %.17g\n", r, best, brute); }
         }
     }
     std::printf("rays %ld hits %ld mismatches %ld nodes/ray %.1f tris/ray %.1f tree nodes %llu refs %llu max_leaf %llu\n", rays, hits, mismatches,

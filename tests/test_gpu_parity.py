@@ -73,22 +73,32 @@ def test_synthetic_mesh_scene_matches_oracle(data_dir):
     assert r["gpu"]["rays"] > 2 * r["n"]      # glass: secondary + shadow rays are really traced
 
 
-def test_full_size_bench_scene_matches_oracle(data_dir, synthetic_sha):
+@pytest.mark.parametrize("kd_build", [1, 0])
+def test_full_size_bench_scene_matches_oracle(data_dir, synthetic_sha, kd_build):
     """BASELINE configs[4] at FULL size (10 035 200 triangles, 3840x2160, maxTraceDepth 8, forest cubemap): the very scene
     bench.py times.  The whole frame is rendered on the device with primary hits; a strided 1/64 pixel subset
     (SURVEY.md 8(d) input 5) is compared with the oracle -- hit node / triangle / bits of the distance inside the 0.01 %
     near-tie budget, colour <= 1e-4 -- and the ray population (radiance, shadow, depth-killed) on four rectangles.
-    Exercises what the miniature cannot: 28-bit record indices, > 4 GB leaf_verts offsets, a 46 M node tree, deep stacks."""
+    Exercises what the miniature cannot: 28-bit record indices, multi-GB leaf_verts offsets, deep stacks -- with the device
+    tree built from the triangles (kd_build 1, the default: 20 M nodes) and with the caller's midpoint planes kept and
+    refined (kd_build 0: 46 M nodes, 34 M leaf references)."""
     from conftest import synthetic_vertex_sha256
     s = host.Scene.synthetic(2240, seed=42, width=3840, height=2160, max_trace_depth=8,
                              env_folder=os.path.join(data_dir, "env", "forest"))
     assert s.desc.n_tris == 10035200
     assert synthetic_vertex_sha256(s) == synthetic_sha["n2240"]["sha256"]
     W, H = 3840, 2160
-    ds = device.DeviceScene(s)
+    device.set_kd_build(kd_build)
+    try:
+        ds = device.DeviceScene(s)
+    finally:
+        device.set_kd_build(1)
     try:
         info = ds.kd_info()
-        assert info["nodes"] > 30_000_000 and info["leaf_refs"] * 72 > 2**31      # really the big tree
+        if kd_build == 0:
+            assert info["nodes"] > 30_000_000 and info["leaf_refs"] * 72 > 2**31      # really the big tree
+        else:
+            assert 10_000_000 < info["nodes"] < 30_000_000 and info["leaf_refs"] >= 10_035_200
         rgb, (hn, ht, hd), st = ds.render(hits=True)
         assert st["primary_rays"] == W * H and st["rays"] > 2 * W * H
         ys, xs = np.meshgrid(np.arange(5, H, 8), np.arange(3, W, 8), indexing="ij")
@@ -346,32 +356,42 @@ def test_full_aa_and_bucket_border_dependency(load_scene):
 
 
 # ---------------------------------------------------------------- device KD tree options
-def test_callers_tree_and_refined_tree_give_the_same_hits(load_scene):
-    """qd_set_kd_refine(0, .) walks the caller's leaves (up to 19 triangles each), the default splits them further:
-    same closest hits bit for bit, far fewer triangle tests."""
+def test_callers_tree_refined_tree_and_rebuilt_tree_give_the_same_hits(load_scene):
+    """qd_set_kd_refine(0, .) walks the caller's leaves (up to 19 triangles each); qd_set_kd_build(0) keeps the caller's
+    planes and splits the leaves further; qd_set_kd_build(1), the default, builds the device tree from the triangles by
+    the surface-area heuristic: same closest hits bit for bit, far fewer triangle tests."""
     s = load_scene("kdtree_fixed.qdmg")
     s.settings.want_aa = 0
     out = {}
     try:
-        for max_leaf in (0, 2):
+        for name, (max_leaf, build) in {"caller": (0, 0), "refined": (2, 0), "rebuilt": (2, 1)}.items():
             device.set_kd_refine(max_leaf, 0.6)
+            device.set_kd_build(build)
             ds = device.DeviceScene(s)
             try:
                 device.set_counting(True)
                 rgb, (hn, ht, hd), st = ds.render(400, 300, 800, 600, hits=True)
-                out[max_leaf] = (rgb, hn, ht, hd, st, ds.kd_info())
+                out[name] = (rgb, hn, ht, hd, st, ds.kd_info())
             finally:
                 device.set_counting(False)
                 ds.close()
     finally:
         device.set_kd_refine(2, 0.6)
-    (rgb0, hn0, ht0, hd0, st0, info0), (rgb2, hn2, ht2, hd2, st2, info2) = out[0], out[2]
+        device.set_kd_build(1)
+    rgb0, hn0, ht0, hd0, st0, info0 = out["caller"]
     assert (ht0 >= 0).sum() > 1000                       # the mesh is really in view
-    assert np.array_equal(hn0, hn2) and np.array_equal(ht0, ht2)
-    assert np.array_equal(hd0.view(np.uint64), hd2.view(np.uint64))
-    assert np.abs(rgb0 - rgb2).max() <= SUM_ORDER_TOL
+    for name in ("refined", "rebuilt"):
+        rgb, hn, ht, hd, st, info = out[name]
+        assert np.array_equal(hn0, hn) and np.array_equal(ht0, ht), name
+        assert np.array_equal(hd0.view(np.uint64), hd.view(np.uint64)), name
+        assert np.abs(rgb0 - rgb).max() <= SUM_ORDER_TOL, name
+        assert st["tris_tested"] * 1.5 < st0["tris_tested"], (name, st["tris_tested"], st0["tris_tested"])
     assert info0["leaf_refs"] == round(s.kd_stats(0)["avg_tris"] * s.kd_stats(0)["leaves"]) and info0["max_leaf"] <= 20
-    assert info2["nodes"] > info0["nodes"] and st2["tris_tested"] * 1.5 < st0["tris_tested"], (info0, info2, st0["tris_tested"], st2["tris_tested"])
+    assert out["refined"][5]["nodes"] > info0["nodes"]
+    # the reference's midpoint builder duplicates straddling triangles down to depth 65 (83 references per triangle here);
+    # the heuristic stops where a split no longer pays
+    assert out["rebuilt"][5]["leaf_refs"] < info0["leaf_refs"] // 4
+    assert out["rebuilt"][4]["kd_nodes_visited"] < out["refined"][4]["kd_nodes_visited"]
 
 
 def test_frame_renderer_runs_the_aa_pass_on_the_gathered_frame(load_scene):
