@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames enqueued at a time, one HIP stream each (1 = strictly one after the other; 0 = by shard size: 2 at 1 GPU, 3 at 2, 4 at 4, 6 beyond)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=None, help="qd_set_pipeline: 0 = one kernel with per-lane queues, 1 = wavefront (default = library default)")
+    ap.add_argument("--pipeline", type=int, default=None, help="qd_set_pipeline: 0 = one kernel with per-lane queues, 1 = wavefront, 2 = the faster of the two, measured (library default)")
     ap.add_argument("--kd-build", type=int, default=None, help="qd_set_kd_build: 1 = device tree by SAH from the triangles, 0 = the caller's planes + refined leaves")
     ap.add_argument("--kd-refine", default=None, help="'max_leaf,step_cost' for qd_set_kd_refine (tuning; default = library default)")
     args = ap.parse_args()
@@ -141,6 +141,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    fr.settle()                    # set-up, untimed: both scheduling forms are timed on this scene, the faster one renders from here on
+    barrier()
     for _ in range(args.warmup):
         fr.submit_frame()
     barrier()
@@ -190,6 +192,9 @@ def main():
     alg_bytes = per_visit * cstats["kd_nodes_visited"] + per_test * cstats["tris_tested"] + 12.0 * owned_px
 
     if rank == 0:
+        form = fr.dscene.schedule_info()["form"]
+        n_kd = sum(1 for i in range(scene.desc.n_nodes) if scene.desc.geoms[scene.desc.nodes[i].geom].type == 5 and scene.desc.meshes[scene.desc.geoms[scene.desc.nodes[i].geom].a].kd_root >= 0)
+        launches = 3 if form == 0 else (scene.settings.max_trace_depth + 2) * (n_kd + 1)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -206,12 +211,14 @@ def main():
             "config": {"workload": workload, "width": W, "height": H, "rays_per_frame": int(rays_frame),
                        "primary_rays": int(rays_local[1].item()), "shadow_rays": int(rays_local[2].item()),
                        "parallelism": f"tiles{args.tile}x{args.tile} interleaved over {world} rank(s), RCCL gather to rank 0",
-                       "frames_in_flight": args.frames_in_flight},
+                       "frames_in_flight": args.frames_in_flight, "schedule": fr.dscene.schedule_info()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "trace_kernel", "kernel_ms": kernel_ms, "launches_per_step": 3,
-                         "launch_avg_ms": kernel_ms / 3.0,   # = rocprofv3's AverageNs of trace_kernel<false> in the --frames-in-flight 1 trace
-                         "note": "one frame = 3 launches of trace_kernel (pixels, then two passes over handed-over ray tasks, usually empty); kernel_ms, achieved and traffic are per frame = the sum over the three, measured on launches that run alone (a separate untimed loop after the timed region; rocprofv3 of `bench.py --frames-in-flight 1`: TotalDurationNs / frames); the timed region overlaps frames, so ms_per_step can be below kernel_ms",
+                         "kernel": "trace_kernel" if form == 0 else "wf_walk_kernel + wf_shade_kernel", "kernel_ms": kernel_ms,
+                         "launches_per_step": launches, "launch_avg_ms": kernel_ms / launches,
+                         "note": ("one frame = 3 launches of trace_kernel (pixels, then two passes over handed-over ray tasks, usually empty)" if form == 0 else
+                                  "one frame = (maxTraceDepth + 2) x (one wf_walk_kernel launch per KD-mesh node + one wf_shade_kernel launch)") +
+                                 "; kernel_ms, achieved and traffic are per frame = the sum over its launches, measured on frames that run alone (a separate untimed loop after the timed region; rocprofv3 of `bench.py --frames-in-flight 1`: TotalDurationNs / frames); the timed region overlaps frames, so ms_per_step can be below kernel_ms",
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_visit_and_test": [per_visit, per_test],
                          "kd_nodes_visited": cstats["kd_nodes_visited"], "tris_tested": cstats["tris_tested"]},
         }

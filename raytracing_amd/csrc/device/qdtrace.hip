@@ -882,7 +882,7 @@ unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};     // device address of 
 int g_device = -1;
 int g_num_cu = 0;
 bool g_counting = false;
-int g_pipeline = 0;           // qd_set_pipeline: 0 = one persistent kernel with per-lane LIFO queues, 1 = wavefront pipeline (wavefront.h)
+int g_pipeline = 2;           // qd_set_pipeline: 0 = one persistent kernel with per-lane LIFO queues, 1 = wavefront pipeline (wavefront.h), 2 = the faster of the two, measured per scene
 int g_refine_leaf = 2;        // qd_set_kd_refine
 double g_refine_cost = 0.6;
 int g_kd_build = 1;           // qd_set_kd_build: 0 = the caller's planes, leaves refined; 1 = whole tree by the surface-area heuristic
@@ -914,6 +914,10 @@ struct WorkSet {
     uint2* wf_deep = nullptr;
     size_t wf_cap = 0;
     uint32_t wf_gens = 0;
+    // adaptive choice of the scheduling form (qd_set_pipeline 2): events around the set's last frame
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    int timed_form = -1;                     // which form that frame ran in, -1 = nothing to read
+    uint64_t timed_slots = 0;
 };
 
 // State of an AA pass between its three steps (mark / trace the taps / combine + resolve), see aa_begin.
@@ -939,6 +943,11 @@ struct qd_scene {
     int geom_mask = 7;                   // kGeomHf | kGeomCsg | kGeomPrim | kGeomCsgDeep as present in the scene: selects the kernel copy
     bool rich = true;                    // bitmap / Mandelbrot / procedural textures or bump maps present
     std::vector<int> kd_node_list;       // scene nodes whose geometry is a mesh with a KD tree: one walk launch each (wavefront pipeline)
+    // adaptive choice of the scheduling form: nanoseconds per pixel slot measured for each form (0 = not tried yet)
+    double form_ns[2] = {0., 0.};
+    uint64_t form_frames = 0;
+    bool wavefront_overflowed = false;
+    int last_form = 0;                   // form of the most recent launch (the synchronous entry points retry an overflowed wavefront frame in the other)
     uint64_t kd_nodes = 0, kd_refs = 0, kd_leaves = 0, kd_max_leaf = 0;   // device tree after refinement
 };
 
@@ -969,6 +978,8 @@ void free_set(WorkSet& w) {
     for (int i = 0; i < 2; ++i) if (w.lists[i]) (void)hipFree(w.lists[i]);
     for (void* p : {(void*)w.wf_ray[0], (void*)w.wf_ray[1], (void*)w.wf_res, (void*)w.wf_ctl, (void*)w.wf_deep}) if (p) (void)hipFree(p);
     if (w.idle) (void)hipEventDestroy(w.idle);
+    if (w.t0) (void)hipEventDestroy(w.t0);
+    if (w.t1) (void)hipEventDestroy(w.t1);
     w = WorkSet();
 }
 
@@ -1078,10 +1089,48 @@ int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hip
     return 0;
 }
 
+int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hipStream_t stream);
+
+// Adaptive choice (qd_set_pipeline 2, the default): which form is faster depends on the frame -- the wavefront form wins
+// where rays have very different fates (a glass object in front of a backdrop: the reference's kdtree_test, 2x), the
+// one-kernel form where every pixel carries similar work (the 10 M triangle terrain, 1.3x).  So each form is timed on
+// real frames of the scene (HIP events around the launches of a working set, read when the set is used next) and
+// the faster one renders; every 64th frame goes to the other one, so that a change of camera or settings is noticed.
+int choose_form(qd_scene* s, WorkSet* w) {
+    if (w->timed_form >= 0 && w->t1 && hipEventQuery(w->t1) == hipSuccess) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, w->t0, w->t1) == hipSuccess && w->timed_slots) {
+            const double ns = (double)ms * 1e6 / (double)w->timed_slots;
+            double& acc = s->form_ns[w->timed_form];
+            acc = acc == 0. ? ns : 0.75 * acc + 0.25 * ns;
+        }
+        w->timed_form = -1;
+    }
+    if (g_pipeline != 2) return g_pipeline;
+    if (s->kd_node_list.size() > kWfMaxKdNodes || s->wavefront_overflowed) return 0;
+    const uint64_t k = s->form_frames++;
+    if (s->form_ns[0] == 0.) return 0;
+    if (s->form_ns[1] == 0.) return 1;
+    const int best = s->form_ns[1] < s->form_ns[0] ? 1 : 0;
+    return (k % 64 == 63) ? 1 - best : best;
+}
+
 int launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream) {
     WorkSet* w = nullptr;
     if (acquire_set(s, stream, max_depth, &w)) return -1;
-    if (g_pipeline == 1 && s->kd_node_list.size() <= kWfMaxKdNodes) return launch_wavefront(s, w, P, max_depth, stream);
+    const int form = choose_form(s, w);
+    if (!w->t0) { HIP_TRY(hipEventCreate(&w->t0)); HIP_TRY(hipEventCreate(&w->t1)); }
+    HIP_TRY(hipEventRecord(w->t0, stream));
+    const int rc = (form == 1 && s->kd_node_list.size() <= kWfMaxKdNodes) ? launch_wavefront(s, w, P, max_depth, stream)
+                                                                           : launch_one_kernel(s, w, P, max_depth, stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(w->t1, stream));
+    w->timed_form = form; w->timed_slots = (uint64_t)P.n_units * kUnitPx;
+    s->last_form = form;
+    return 0;
+}
+
+int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hipStream_t stream) {
     P.stack = w->stack; P.stack_cap = w->stack_cap; P.n_lanes = s->n_lanes;
     P.error_flag = s->error_flag;
     P.list_cap = w->list_cap;
@@ -1162,7 +1211,7 @@ extern "C" int qd_set_kd_build(int mode) {
 }
 
 extern "C" int qd_set_pipeline(int pipeline) {
-    if (pipeline != 0 && pipeline != 1) return set_err("qd_set_pipeline: 0 (one kernel, per-lane queues) or 1 (wavefront)");
+    if (pipeline < 0 || pipeline > 2) return set_err("qd_set_pipeline: 0 (one kernel, per-lane queues), 1 (wavefront) or 2 (the faster of the two, measured)");
     g_pipeline = pipeline;
     return 0;
 }
@@ -1179,6 +1228,14 @@ extern "C" int qd_scene_kd_info(const qd_scene* s, uint64_t* nodes, uint64_t* le
     if (leaf_refs) *leaf_refs = s->kd_refs;
     if (leaves) *leaves = s->kd_leaves;
     if (max_leaf) *max_leaf = s->kd_max_leaf;
+    return 0;
+}
+
+extern "C" int qd_scene_schedule_info(const qd_scene* s, int* last_form, double* ns_per_pixel_form0, double* ns_per_pixel_form1) {
+    if (!s) return set_err("qd_scene_schedule_info: null scene");
+    if (last_form) *last_form = s->last_form;
+    if (ns_per_pixel_form0) *ns_per_pixel_form0 = s->form_ns[0];
+    if (ns_per_pixel_form1) *ns_per_pixel_form1 = s->form_ns[1];
     return 0;
 }
 
@@ -1451,14 +1508,16 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
     float ms = 0; TRY2(hipEventElapsedTime(&ms, e0, e1));
     int err_flag = 0;
     TRY2(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (err_flag && g_pipeline == 1) {
+    if (err_flag && s->last_form == 1) {
         // a generation outgrew the wavefront queues (a rectangle full of glass): the same call in the one-kernel form
+        s->wavefront_overflowed = true;
+        const int saved_pipeline = g_pipeline;
         TRY2(hipMemsetAsync(s->stats, 0, 24 * sizeof(unsigned long long), nullptr));
         TRY2(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
         TRY2(hipEventRecord(e0, nullptr));
         g_pipeline = 0;
         rc = launch(s, P, st->max_trace_depth, nullptr);
-        g_pipeline = 1;
+        g_pipeline = saved_pipeline;
         if (rc) { cleanup(); return -1; }
         TRY2(hipEventRecord(e1, nullptr));
         TRY2(hipEventSynchronize(e1));
@@ -1639,15 +1698,17 @@ int antialias_impl(qd_scene* s, const qd_camera* cam, const qd_settings* st, flo
         TRY2(hipEventRecord(e1, nullptr));
         TRY2(hipEventSynchronize(e1));
         TRY2(hipEventElapsedTime(&ms, e0, e1));
-        if (g_pipeline == 1) {                  // taps that outgrew the wavefront queues: once more in the one-kernel form
+        if (s->last_form == 1) {                // taps that outgrew the wavefront queues: once more in the one-kernel form
             int err_flag = 0;
             TRY2(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
             if (err_flag == 1) {
+                s->wavefront_overflowed = true;
+                const int saved_pipeline = g_pipeline;
                 TRY2(hipMemsetAsync(s->stats, 0, 16 * sizeof(unsigned long long), nullptr));
                 TRY2(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
                 g_pipeline = 0;
                 const int rc2 = aa_trace(s, cam, st, 0, n_list, d_taps, s->stats, nullptr);
-                g_pipeline = 1;
+                g_pipeline = saved_pipeline;
                 if (rc2) { cleanup(); return -1; }
                 TRY2(hipDeviceSynchronize());
             }
@@ -1807,7 +1868,14 @@ extern "C" int qd_scene_check(qd_scene* s) {
     if (!s) return set_err("qd_scene_check: null scene");
     int f = 0;
     HIP_TRY(hipMemcpy(&f, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (f) { (void)hipMemset(s->error_flag, 0, sizeof(int)); return set_err("ray queue overflow on device"); }
+    if (f) {
+        (void)hipMemset(s->error_flag, 0, sizeof(int));
+        if (s->last_form == 1) {       // a generation outgrew the wavefront queues: this scene stays on the one-kernel form from here on
+            s->wavefront_overflowed = true;
+            return set_err("ray queue overflow on device (wavefront form; the scene's next frames use the one-kernel form, whose queues cannot overflow)");
+        }
+        return set_err("ray queue overflow on device");
+    }
     return 0;
 }
 

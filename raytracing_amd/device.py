@@ -47,6 +47,7 @@ def lib():
         L.qd_set_kd_refine.argtypes = [C.c_int, C.c_double]
         L.qd_set_pipeline.argtypes = [C.c_int]
         L.qd_set_kd_build.argtypes = [C.c_int]
+        L.qd_scene_schedule_info.argtypes = [C.c_void_p, P(C.c_int), P(C.c_double), P(C.c_double)]
         L.qd_scene_kd_info.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
         L.qd_comm_unique_id.argtypes = [C.c_void_p]
         L.qd_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
@@ -91,7 +92,8 @@ def set_kd_build(mode):
 
 
 def set_pipeline(pipeline):
-    """0 = one persistent kernel with per-lane ray queues, 1 = wavefront pipeline (generations of rays in HBM queues)."""
+    """0 = one persistent kernel with per-lane ray queues, 1 = wavefront pipeline (generations of rays in HBM queues),
+    2 = the faster of the two, measured per scene (library default)."""
     _check(lib().qd_set_pipeline(pipeline), "qd_set_pipeline")
 
 
@@ -212,6 +214,12 @@ class DeviceScene:
 
     def check(self):
         _check(lib().qd_scene_check(self._h), "qd_scene_check")
+
+    def schedule_info(self):
+        """The adaptive choice of the scheduling form: form of the last launch, measured ns per pixel of each form."""
+        f, a, b = C.c_int(), C.c_double(), C.c_double()
+        _check(lib().qd_scene_schedule_info(self._h, C.byref(f), C.byref(a), C.byref(b)), "qd_scene_schedule_info")
+        return {"form": int(f.value), "ns_per_pixel": [float(a.value), float(b.value)]}
 
     def kd_info(self):
         v = [C.c_uint64() for _ in range(4)]

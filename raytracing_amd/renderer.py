@@ -131,6 +131,14 @@ class FrameRenderer:
                 self.gather(k)
         return k
 
+    def settle(self, frames=None):
+        """Untimed set-up: lets the library time both scheduling forms on this scene's real frames (qd_set_pipeline 2) so
+        that the frames that follow run in the faster one.  Every rank must call it (the frames are gathered)."""
+        for _ in range(frames if frames is not None else 2 * self.F + 4):
+            self.submit_frame()
+        self.wait()
+        torch.cuda.synchronize(self.dev)
+
     def wait(self, slot=None):
         """Host-wait for one slot's stream (or all of them) and return that slot's frame (rank 0) or None."""
         for k, sl in enumerate(self.slots):
