@@ -36,7 +36,7 @@ def build_scene(args):
         env = os.path.join(data, "env", "forest")
         scene = host.Scene.synthetic(args.mesh_n, seed=42, width=args.width, height=args.height,
                                      max_trace_depth=args.depth, env_folder=env)
-        name = (f"synthetic displaced-grid glass mesh, {scene.desc.n_tris} triangles, midpoint KD-tree from the host builder + device SAH refinement, "
+        name = (f"synthetic displaced-grid glass mesh, {scene.desc.n_tris} triangles, device KD-tree built from the triangles by SAH, "
                 f"{args.width}x{args.height}, maxTraceDepth {args.depth}, forest cubemap (BASELINE configs[4])")
     else:
         scene = host.Scene.load(os.path.join(data, args.workload))
@@ -197,10 +197,11 @@ def main():
         launches = 3 if form == 0 else (scene.settings.max_trace_depth + 2) * (n_kd + 1)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and world == 1 and args.workload == "synth" and args.mesh_n == 2240:
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")          # PMC sums of a separate rocprofv3 --pmc run (scripts/gpu_profile.sh)
+        tkey = {"synth": "synth10m_4k" if (args.mesh_n, W, H) == (2240, 3840, 2160) else None}.get(args.workload, f"{os.path.basename(args.workload).split('.')[0]}_{W}x{H}")
+        if os.path.exists(tpath) and world == 1 and tkey:
             try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
+                traffic = json.load(open(tpath)).get(tkey, {}).get("bytes_per_frame")
             except Exception:
                 traffic = None
         out = {

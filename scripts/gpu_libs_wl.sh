@@ -1,9 +1,9 @@
 #!/bin/bash
-# several builds x several workloads, pipeline 1, one frame at a time.  usage: scripts/gpu_libs_wl.sh lib1.so lib2.so ...
+# several builds x several workloads (PIPE = scheduling form, default 1; FIF = frames in flight, default 1).  usage: scripts/gpu_libs_wl.sh lib1.so lib2.so ...
 cd "$GRAFT_REPO_ROOT"
 for wl in "" "--workload kdtree_fixed.qdmg" "--workload lecture7_fixed.qdmg --width 3840 --height 2160" "--workload heightfield_fixed.qdmg --width 3840 --height 2160"; do
   for lib in "$@"; do
-    timeout -k 10 200 python -u scripts/ab_bench.py $PWD/$lib --pipeline 1 --frames-in-flight 1 --steps 6 --warmup 2 --no-cpu-baseline $wl > gpurun_out/libs.log 2>gpurun_out/libs.err || { tail -5 gpurun_out/libs.err; exit 1; }
+    timeout -k 10 200 python -u scripts/ab_bench.py $PWD/$lib --pipeline ${PIPE:-1} --frames-in-flight ${FIF:-1} --steps 6 --warmup 2 --no-cpu-baseline $wl > gpurun_out/libs.log 2>gpurun_out/libs.err || { tail -5 gpurun_out/libs.err; exit 1; }
     tail -1 gpurun_out/libs.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$wl | $lib', round(d['value']/1e6,1),'Mrays/s', round(d['ms_per_step'],2),'ms/frame')"
   done
 done
