@@ -625,7 +625,8 @@ template <int D> QD_DEV bool geom_inside_t(const DScene& S, int gi, const DV& p)
 // Closest hit of one non-CSG geometry of any kind, as a full record.  A mesh hit carries triangle + barycentrics (its
 // normal / uv are derived once for the winner by mesh_finish in assemble_info).
 template <bool STATS>
-__device__ __attribute__((noinline)) bool leaf_any_intersect(const DScene& S, int gi, const DV& start, const DV& dir, GHit& out, Counters& cnt) {
+__device__ __attribute__((noinline)) bool leaf_any_intersect(const DScene& S_, int gi, const DV& start, const DV& dir, GHit& out, Counters& cnt) {
+    const DScene& S = uniform_const(S_);
     const qd_geom g = S.geoms[gi];
     if (g.type == QD_GEOM_MESH) {
         const MHit mh = mesh_query<STATS>(mesh_data(S), g.a, start, dir, false, 0., 1.);
@@ -657,7 +658,8 @@ QD_DEV bool geom_any_intersect(const DScene& S, int gi, const DV& start, const D
 
 // CsgOp::Intersect (src/geometry.cpp:184-234) for the CSG geometry gi whose operands may nest D more levels.
 template <bool STATS, int D>
-__device__ __attribute__((noinline)) bool csg_generic(const DScene& S, int gi, const DV& start, const DV& dir, GHit& out, Counters& cnt) {
+__device__ __attribute__((noinline)) bool csg_generic(const DScene& S_, int gi, const DV& start, const DV& dir, GHit& out, Counters& cnt) {
+    const DScene& S = uniform_const(S_);
     const qd_geom g = S.geoms[gi];
     GHit li, ri;
     li.tri = ri.tri = -1;

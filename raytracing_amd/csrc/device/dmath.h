@@ -9,6 +9,15 @@
 
 #define QD_DEV __device__ __forceinline__
 
+// A reference to constant data that every lane of the wave addresses alike (the scene description, the launch parameters),
+// for a function that is not inlined: the address is made wave-uniform and the data read from the constant address space,
+// i.e. with scalar loads (see kernarg_scene in qdtrace.hip).
+template <class T> QD_DEV const T& uniform_const(const T& r) {
+    const uint64_t a = (uint64_t)&r;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    typedef const T __attribute__((address_space(4))) * ConstPtr;
+    return *(const T*)(ConstPtr)(((uint64_t)hi << 32) | (uint64_t)lo);
+}
 namespace qd {
 
 constexpr double kPi = 3.141592653589793238;   // src/constants.h:10

@@ -96,6 +96,21 @@ struct Task {
     uint32_t pixel;               // output slot the ray's colour is added to (a task may be traced by any lane of the wave)
 };
 
+// The kernels take the scene and the launch parameters by value; a function that is NOT inlined into a kernel takes them
+// by reference.  A reference to the kernel's by-value parameter would make the compiler copy the whole struct to scratch
+// memory in every wave's prologue (0.6 KB per lane) and read its fields back lane by lane; instead the kernel hands out a
+// reference to the argument as it lies in the kernel-argument segment (ordinary constant memory: explicit arguments start
+// at offset 0, each at its natural alignment), and the callee reads it through uniform_const: address made wave-uniform,
+// constant address space -> scalar loads (dmath.h).  kernarg_scene / kernarg_params are for code that is inlined into a
+// KERNEL: in a function behind a real call the compiler resolves the kernel-argument pointer to null.
+constexpr size_t kParamsKernarg = (sizeof(DScene) + alignof(Params) - 1) / alignof(Params) * alignof(Params);
+QD_DEV const DScene& kernarg_scene() {
+    return *(const DScene*)(const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+}
+QD_DEV const Params& kernarg_params() {
+    return *(const Params*)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + kParamsKernarg);
+}
+
 QD_DEV uint64_t pack2f(float a, float b) { return (uint64_t)__float_as_uint(a) | ((uint64_t)__float_as_uint(b) << 32); }
 QD_DEV uint64_t pack_fu(float a, uint32_t b) { return (uint64_t)__float_as_uint(a) | ((uint64_t)b << 32); }
 
@@ -147,8 +162,9 @@ struct LaneQueue {
 // kGeomCsgDeep: a CSG node whose operands are not all analytic primitives (another CSG, a mesh, a heightfield): csg_generic.
 constexpr int kGeomHf = 1, kGeomCsg = 2, kGeomPrim = 4, kGeomCsgDeep = 8, kGeomAll = 15;
 template <bool STATS, int GEOM>
-__device__ QD_OUTLINE int trace_nodes(const DScene& S, const DV& o, const DV& d, bool shadow, double target,
+__device__ QD_OUTLINE int trace_nodes(const DScene& S_, const DV& o, const DV& d, bool shadow, double target,
                        float& transp, double& best_dw, GHit& hit, Counters& cnt) {
+    const DScene& S = uniform_const(S_);
     int best_node = -1;
     best_dw = kInf; transp = 1.f;
     double w_dist = 0, w_l2 = 0, w_l3 = 0;
@@ -244,12 +260,21 @@ __device__ QD_OUTLINE void eval_nested_layered(const DScene& S, const Params& P,
 // Queue: where child rays go -- the lane's LIFO queue (one-kernel form) or the next generation's queue (wavefront form).
 // The body is inlined into the wavefront shading kernel (its own kernel, 2 waves per SIMD: +10 .. +30 % there) and sits
 // behind a real call in the one-kernel form (eval_leaf_shader below: the traversal's register allocation stays small).
+// S_mem / P_mem: the scene and the parameters as they lie in memory, for the one call made from here (see kernarg_scene).
 template <bool NESTED, bool RICH, class Queue>
-QD_DEV void eval_leaf_shader_body(const DScene& S, const Params& P, int si, Col w, uint32_t slot, const Task& ray, uint32_t depth,
-                                  const Info& info, Col& acc, Queue& q) {
+QD_DEV void eval_leaf_shader_body(const DScene& S, const Params& P, const DScene& S_mem, const Params& P_mem, int si, Col w, uint32_t slot,
+                                  const Task& ray, uint32_t depth, const Info& info, Col& acc, Queue& q) {
     const qd_shader sh = S.shaders[si];
     switch (sh.type) {
-        case QD_SH_LAYERED: if (NESTED) eval_nested_layered<RICH, Queue>(S, P, sh, w, slot, ray, depth, info, acc, q); break;
+        case QD_SH_LAYERED:
+            if (NESTED) {
+                // a rare path behind a real call: it works on copies, so that the caller's ray, hit record, colour and queue
+                // state do not have their addresses taken (they would live in scratch memory for the whole kernel)
+                const Task ray2 = ray; const Info info2 = info; Col acc2 = acc; Queue q2 = q; const qd_shader sh2 = sh;
+                eval_nested_layered<RICH, Queue>(S_mem, P_mem, sh2, w, slot, ray2, depth, info2, acc2, q2);
+                acc = acc2; q = q2;
+            }
+            break;
         case QD_SH_CONST: acc = acc + w * ldc(sh.color); break;
         case QD_SH_LAMBERT: case QD_SH_PHONG: case QD_SH_BLINNPHONG: case QD_SH_ORENNAYAR: {
             const Col diffuse = sh.tex >= 0 ? tex_sample<RICH>(S, sh.tex, info) : ldc(sh.color);
@@ -353,16 +378,18 @@ QD_DEV void eval_leaf_shader_body(const DScene& S, const Params& P, int si, Col 
 }
 
 template <bool NESTED, bool RICH, class Queue>
-__device__ QD_OUTLINE void eval_leaf_shader(const DScene& S, const Params& P, int si, Col w, uint32_t slot, const Task& ray, uint32_t depth,
+__device__ QD_OUTLINE void eval_leaf_shader(const DScene& S_, const Params& P_, int si, Col w, uint32_t slot, const Task& ray, uint32_t depth,
                              const Info& info, Col& acc, Queue& q) {
-    eval_leaf_shader_body<NESTED, RICH, Queue>(S, P, si, w, slot, ray, depth, info, acc, q);
+    const DScene& S = uniform_const(S_); const Params& P = uniform_const(P_);
+    eval_leaf_shader_body<NESTED, RICH, Queue>(S, P, S_, P_, si, w, slot, ray, depth, info, acc, q);
 }
 
 // Layered::Shade (src/shading.cpp:260-275) for a Layered that is a layer of another one: the same suffix-product walk as
 // in the kernel, one stack frame per nesting level.  A layer's path-id slot is parent_slot * 32 + i + 1 (the oracle's rule).
 template <bool RICH, class Queue>
-__device__ QD_OUTLINE void eval_nested_layered(const DScene& S, const Params& P, const qd_shader& top, Col w, uint32_t slot, const Task& ray,
+__device__ QD_OUTLINE void eval_nested_layered(const DScene& S_, const Params& P_, const qd_shader& top, Col w, uint32_t slot, const Task& ray,
                                                uint32_t depth, const Info& info, Col& acc, Queue& q) {
+    const DScene& S = uniform_const(S_); const Params& P = uniform_const(P_);
     struct Frame { int i0, i; uint32_t slot; Col w, suffix; };
     Frame st[kMaxLayerNesting];
     int sp = 0;
@@ -648,7 +675,7 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
         GHit h; double dw; float transp;
         const unsigned long long tp1 = QD_STAMP();
         t_sched += tp1 - tp0;
-        const int node = trace_nodes<STATS, GEOM>(S, t.o, t.d, shadow, t.aux0, transp, dw, h, cnt);
+        const int node = trace_nodes<STATS, GEOM>(kernarg_scene(), t.o, t.d, shadow, t.aux0, transp, dw, h, cnt);
         const unsigned long long tp2 = QD_STAMP();
         t_trace += tp2 - tp1;
         if (shadow) {
@@ -677,11 +704,11 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
                 const qd_layer l = S.layers[top.i0 + i];
                 Col blend = ldc(l.blend);
                 if (l.tex >= 0) blend = blend * tex_sample<RICH>(S, l.tex, info);
-                eval_leaf_shader<true, RICH>(S, P, l.shader, t.w * (blend * suffix), (uint32_t)i + 1, t, depth, info, acc, q);
+                eval_leaf_shader<true, RICH>(kernarg_scene(), kernarg_params(), l.shader, t.w * (blend * suffix), (uint32_t)i + 1, t, depth, info, acc, q);
                 suffix = suffix * (mkc(1.f, 1.f, 1.f) - blend);
             }
         } else {
-            eval_leaf_shader<true, RICH>(S, P, n.shader, t.w, 0, t, depth, info, acc, q);
+            eval_leaf_shader<true, RICH>(kernarg_scene(), kernarg_params(), n.shader, t.w, 0, t, depth, info, acc, q);
         }
         t_shade += QD_STAMP() - tp2;
         } while (false);

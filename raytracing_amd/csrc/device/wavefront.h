@@ -359,7 +359,7 @@ QD_DEV int wf_nodes(const DScene& S, const Params& P, uint32_t ridx, const DV& o
             GHit h;
             if ((GEOM & kGeomCsgDeep) && g.type == QD_GEOM_CSG) {
                 Counters again = cnt;
-                got = csg_generic<STATS, kMaxCsgNesting - 1>(S, n.geom, r.o, r.d, h, final_pass ? again : cnt);
+                got = csg_generic<STATS, kMaxCsgNesting - 1>(kernarg_scene(), n.geom, r.o, r.d, h, final_pass ? again : cnt);
             } else got = analytic_intersect<(GEOM & kGeomCsg) != 0, (GEOM & kGeomPrim) != 0>(S, g, r.o, r.d, h);
             if (final_pass) { hit = h; break; }
             dist = h.dist;
@@ -444,11 +444,11 @@ __global__ __launch_bounds__(64, QD_WF_SHADE_WAVES) void wf_shade_kernel(const D
                 const qd_layer l = S.layers[top.i0 + i];
                 Col blend = ldc(l.blend);
                 if (l.tex >= 0) blend = blend * tex_sample<RICH>(S, l.tex, info);
-                eval_leaf_shader_body<true, RICH>(S, P, l.shader, t.w * (blend * suffix), (uint32_t)i + 1, t, depth, info, acc, q);
+                eval_leaf_shader_body<true, RICH>(S, P, kernarg_scene(), kernarg_params(), l.shader, t.w * (blend * suffix), (uint32_t)i + 1, t, depth, info, acc, q);
                 suffix = suffix * (mkc(1.f, 1.f, 1.f) - blend);
             }
         } else {
-            eval_leaf_shader_body<true, RICH>(S, P, n.shader, t.w, 0, t, depth, info, acc, q);
+            eval_leaf_shader_body<true, RICH>(S, P, kernarg_scene(), kernarg_params(), n.shader, t.w, 0, t, depth, info, acc, q);
         }
         add_px(P, t.pixel, acc);
     }
