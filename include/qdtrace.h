@@ -238,12 +238,26 @@ int qd_scene_create(const qd_scene_desc* desc, qd_scene** out);
  *                     packed (y-y0)*(x1-x0)+(x-x0): node index (-1 = sky), mesh-local
  *                     triangle index (-1 for non-mesh), world-space distance.
  *   stats           : optional.
- * Returns 0, or <0 and sets qd_last_error(). */
+ * Returns 0, or <0 and sets qd_last_error().  Device staging for the rectangle, the hit planes and the timing events
+ * belongs to the scene handle and is reused from call to call (grown when a larger rectangle comes). */
 int qd_render(qd_scene* scene, const qd_camera* camera, const qd_settings* settings,
               int x0, int y0, int x1, int y1,
               float* rgb, size_t row_pitch_floats,
               int32_t* hit_node, int32_t* hit_tri, double* hit_dist,
               qd_stats* stats);
+
+/* Replaces: RenderScene's bucket loop (src/main.cpp:85-104: for each 48 x 48 bucket of GetBucketList, src/sdl.cpp:253-276,
+ * trace its pixels, then DisplayVFBRect(bucket)) without a launch per bucket.  qd_frame_begin enqueues the WHOLE first
+ * pass of the frame on `hip_stream` (NULL = default stream) into a buffer the scene handle keeps, and returns at once.
+ * qd_frame_read_rect copies the finished rectangle [x0,x1) x [y0,y1) to the caller's HOST buffer (pixel (x,y) at
+ * rgb[(y-y0)*row_pitch_floats + (x-x0)*3]): the first read after qd_frame_begin waits for the frame and fetches it to
+ * a pinned host copy in one transfer, every read is then a copy of rows on the host -- so the reference's loop keeps its
+ * shape (read a bucket, display it) at the cost of one frame-sized launch.  qd_frame_end returns the frame's counters
+ * (optional) and ends the plan; a new qd_frame_begin also ends it.  Values are those of qd_render(0,0,W,H).
+ * One frame at a time per scene handle; errors of the launch (ray queue overflow) surface at the first read. */
+int qd_frame_begin(qd_scene* scene, const qd_camera* camera, const qd_settings* settings, void* hip_stream);
+int qd_frame_read_rect(qd_scene* scene, int x0, int y0, int x1, int y1, float* rgb, size_t row_pitch_floats);
+int qd_frame_end(qd_scene* scene, qd_stats* stats);
 
 /* Replaces: the anti-aliasing pass of RenderScene (src/main.cpp:106-153, IsTooDifferent :58-83), which
  * the reference runs after SimpleRender when settings.wantAA is set.

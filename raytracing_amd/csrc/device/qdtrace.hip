@@ -957,9 +957,34 @@ struct AaPlan {
     bool traced = false;           // false: nothing listed, or showAA (marks are painted, no taps)
 };
 
+// Buffers the synchronous entry points stage their data in (qd_render's rectangle and hit planes, the anti-aliasing pass's
+// frame copies, lists and flags, the frame of qd_frame_begin): held by the scene handle, grown when a call needs more,
+// freed by qd_scene_destroy -- a loop of calls (the reference renders a frame bucket by bucket) allocates once.
+enum { kStRgb, kStHitNode, kStHitTri, kStHitDist, kStAaFrame, kStAaTaps, kStAaFirst, kStAaSlot, kStAaList, kStAaSorted, kStAaTmp,
+       kStAaA, kStAaB, kStAaAa, kStAaFlags, kStFrame, kStCount };
+struct Staging {
+    void* p[kStCount] = {};
+    size_t bytes[kStCount] = {};
+    hipEvent_t e0 = nullptr, e1 = nullptr;       // around the timed launches of a synchronous call
+    void* host_frame = nullptr;                  // pinned copy of the qd_frame_begin frame
+    size_t host_bytes = 0;
+};
+
+// A frame rendered ahead of a loop of rectangle reads (qd_frame_begin / qd_frame_read_rect / qd_frame_end).
+struct FramePlan {
+    int W = 0, H = 0;
+    bool launched = false, fetched = false;
+    hipStream_t stream = nullptr;
+    Params P;
+    uint32_t max_depth = 0;
+    float ms = 0.f;
+};
+
 struct qd_scene {
     DScene d;
     AaPlan aa;
+    Staging stg;
+    FramePlan frame;
     std::vector<void*> allocs;
     uint32_t n_lanes = 0;
     WorkSet sets[kMaxWorkSets];
@@ -1193,6 +1218,56 @@ int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hi
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(w->idle, stream));
+    return 0;
+}
+
+// Staging buffer `which` of at least `bytes` bytes (see Staging).  Growing one frees the old block, which waits for the device.
+int stage(qd_scene* s, int which, size_t bytes, void** out) {
+    Staging& g = s->stg;
+    if (bytes == 0) bytes = 1;
+    if (g.bytes[which] < bytes) {
+        if (g.p[which]) { (void)hipFree(g.p[which]); g.p[which] = nullptr; g.bytes[which] = 0; }
+        HIP_TRY(hipMalloc(&g.p[which], bytes));
+        g.bytes[which] = bytes;
+    }
+    *out = g.p[which];
+    return 0;
+}
+
+// What a synchronous entry point does around its launches: counters and error flag cleared, events around the launches,
+// wait, error flag read; a wavefront frame whose queues overflowed is rendered again in the one-kernel form (whose queues
+// are bounded by construction).  `begin_only` stops after the enqueue (qd_frame_begin); finish_launch does the rest.
+int finish_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream, float* ms);
+int timed_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream, float* ms, bool begin_only = false) {
+    Staging& g = s->stg;
+    if (!g.e0) { HIP_TRY(hipEventCreate(&g.e0)); HIP_TRY(hipEventCreate(&g.e1)); }
+    HIP_TRY(hipMemsetAsync(s->stats, 0, 24 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(s->stats + 16, 0xff, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(s->stats + 19, 0xff, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(s->error_flag, 0, sizeof(int), stream));
+    HIP_TRY(hipEventRecord(g.e0, stream));
+    if (launch(s, P, max_depth, stream)) return -1;
+    HIP_TRY(hipEventRecord(g.e1, stream));
+    return begin_only ? 0 : finish_launch(s, P, max_depth, stream, ms);
+}
+int finish_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream, float* ms) {
+    Staging& g = s->stg;
+    HIP_TRY(hipEventSynchronize(g.e1));
+    if (ms) HIP_TRY(hipEventElapsedTime(ms, g.e0, g.e1));
+    int err_flag = 0;
+    HIP_TRY(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (err_flag == 1 && s->last_form == 1) {
+        s->wavefront_overflowed = true;
+        const int saved_pipeline = g_pipeline;
+        g_pipeline = 0;
+        const int rc = timed_launch(s, P, max_depth, stream, ms);
+        g_pipeline = saved_pipeline;
+        return rc;
+    }
+    if (err_flag) {
+        (void)hipMemset(s->error_flag, 0, sizeof(int));
+        return set_err(err_flag == 2 ? "marked pixel outside the traced set" : "ray queue overflow on device");
+    }
     return 0;
 }
 
@@ -1489,7 +1564,10 @@ extern "C" void qd_scene_destroy(qd_scene* s) {
     if (!s) return;
     for (void* p : s->allocs) (void)hipFree(p);
     for (auto& w : s->sets) free_set(w);
-    for (void* p : {(void*)s->aa.first, (void*)s->aa.slot, (void*)s->aa.list}) if (p) (void)hipFree(p);
+    for (void* p : s->stg.p) if (p) (void)hipFree(p);
+    if (s->stg.host_frame) (void)hipHostFree(s->stg.host_frame);
+    if (s->stg.e0) (void)hipEventDestroy(s->stg.e0);
+    if (s->stg.e1) (void)hipEventDestroy(s->stg.e1);
     if (s->stats) (void)hipFree(s->stats);
     if (s->error_flag) (void)hipFree(s->error_flag);
     delete s;
@@ -1508,50 +1586,17 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
     P.n_units = P.units_x * (uint32_t)((rh + kUnitSide - 1) / kUnitSide);
     const size_t npx = (size_t)rw * rh;
     float* d_rgb = nullptr; int32_t* d_hn = nullptr; int32_t* d_ht = nullptr; double* d_hd = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    int rc = 0;
-    auto cleanup = [&]() {
-        if (d_rgb) (void)hipFree(d_rgb); if (d_hn) (void)hipFree(d_hn); if (d_ht) (void)hipFree(d_ht); if (d_hd) (void)hipFree(d_hd);
-        if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
-    };
+    auto cleanup = []() {};                                  // the staging buffers stay with the scene handle
 #define TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return -1; } } while (0)
-    TRY2(hipMalloc((void**)&d_rgb, npx * 3 * sizeof(float)));
+    if (stage(s, kStRgb, npx * 3 * sizeof(float), (void**)&d_rgb)) return -1;
     if (hit_node) {
-        TRY2(hipMalloc((void**)&d_hn, npx * sizeof(int32_t)));
-        TRY2(hipMalloc((void**)&d_ht, npx * sizeof(int32_t)));
-        TRY2(hipMalloc((void**)&d_hd, npx * sizeof(double)));
+        if (stage(s, kStHitNode, npx * sizeof(int32_t), (void**)&d_hn) || stage(s, kStHitTri, npx * sizeof(int32_t), (void**)&d_ht) ||
+            stage(s, kStHitDist, npx * sizeof(double), (void**)&d_hd)) return -1;
     }
     P.rgb = d_rgb; P.pitch = (size_t)rw * 3; P.rgb_floats = npx * 3; P.hit_node = d_hn; P.hit_tri = d_ht; P.hit_dist = d_hd;
     P.stats = s->stats;
-    TRY2(hipMemsetAsync(s->stats, 0, 24 * sizeof(unsigned long long), nullptr));
-    TRY2(hipMemsetAsync(s->stats + 16, 0xff, sizeof(unsigned long long), nullptr)); TRY2(hipMemsetAsync(s->stats + 19, 0xff, sizeof(unsigned long long), nullptr));
-    TRY2(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
-    TRY2(hipEventCreate(&e0)); TRY2(hipEventCreate(&e1));
-    TRY2(hipEventRecord(e0, nullptr));
-    rc = launch(s, P, st->max_trace_depth, nullptr);
-    if (rc) { cleanup(); return -1; }
-    TRY2(hipEventRecord(e1, nullptr));
-    TRY2(hipEventSynchronize(e1));
-    float ms = 0; TRY2(hipEventElapsedTime(&ms, e0, e1));
-    int err_flag = 0;
-    TRY2(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (err_flag && s->last_form == 1) {
-        // a generation outgrew the wavefront queues (a rectangle full of glass): the same call in the one-kernel form
-        s->wavefront_overflowed = true;
-        const int saved_pipeline = g_pipeline;
-        TRY2(hipMemsetAsync(s->stats, 0, 24 * sizeof(unsigned long long), nullptr));
-        TRY2(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
-        TRY2(hipEventRecord(e0, nullptr));
-        g_pipeline = 0;
-        rc = launch(s, P, st->max_trace_depth, nullptr);
-        g_pipeline = saved_pipeline;
-        if (rc) { cleanup(); return -1; }
-        TRY2(hipEventRecord(e1, nullptr));
-        TRY2(hipEventSynchronize(e1));
-        TRY2(hipEventElapsedTime(&ms, e0, e1));
-        TRY2(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
-    }
-    if (err_flag) { cleanup(); return set_err("qd_render: ray queue overflow on device"); }
+    float ms = 0;
+    if (timed_launch(s, P, st->max_trace_depth, nullptr, &ms)) { set_err(std::string("qd_render: ") + g_err); return -1; }
     if (pitch == (size_t)rw * 3) TRY2(hipMemcpy(rgb, d_rgb, npx * 3 * sizeof(float), hipMemcpyDeviceToHost));      // contiguous rows: one copy
     else TRY2(hipMemcpy2D(rgb, pitch * sizeof(float), d_rgb, (size_t)rw * 3 * sizeof(float), (size_t)rw * 3 * sizeof(float), rh, hipMemcpyDeviceToHost));
     if (hit_node) {
@@ -1586,14 +1631,81 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
 }
 
 
+// ------------------------------------------------------------------------------------------ frame ahead of a bucket loop
+// The reference renders a frame bucket by bucket and shows each bucket as it is done (RenderScene, src/main.cpp:85-104 +
+// DisplayVFBRect).  A launch per 48 x 48 bucket leaves the GPU empty (36 waves) and pays a round trip each; so the whole
+// frame is enqueued once (qd_frame_begin, returns at once), and the bucket loop reads finished rectangles out of it
+// (qd_frame_read_rect: the first read waits for the frame and brings it to a pinned host copy in one transfer, every read
+// is then a copy of rows on the host).
+extern "C" int qd_frame_begin(qd_scene* s, const qd_camera* cam, const qd_settings* st, void* hip_stream) {
+    if (!s || !cam || !st) return set_err("qd_frame_begin: null argument");
+    const int W = st->frame_width, H = st->frame_height;
+    if (W <= 0 || H <= 0) return set_err("qd_frame_begin: frame size out of range");
+    FramePlan& f = s->frame;
+    if (f.launched && !f.fetched) HIP_TRY(hipEventSynchronize(s->stg.e1));      // an abandoned frame: let it drain before its buffer is reused
+    f = FramePlan();
+    float* d_frame = nullptr;
+    const size_t npx = (size_t)W * H;
+    if (stage(s, kStFrame, npx * 3 * sizeof(float), (void**)&d_frame)) return -1;
+    if (s->stg.host_bytes < npx * 3 * sizeof(float)) {
+        if (s->stg.host_frame) { (void)hipHostFree(s->stg.host_frame); s->stg.host_frame = nullptr; s->stg.host_bytes = 0; }
+        HIP_TRY(hipHostMalloc(&s->stg.host_frame, npx * 3 * sizeof(float), hipHostMallocDefault));
+        s->stg.host_bytes = npx * 3 * sizeof(float);
+    }
+    fill_common(f.P, cam, st);
+    f.P.mode = 0; f.P.x0 = 0; f.P.y0 = 0; f.P.rw = W; f.P.rh = H;
+    f.P.units_x = (uint32_t)(W + kUnitSide - 1) / kUnitSide;
+    f.P.n_units = f.P.units_x * (uint32_t)((H + kUnitSide - 1) / kUnitSide);
+    f.P.rgb = d_frame; f.P.pitch = (size_t)W * 3; f.P.rgb_floats = npx * 3; f.P.stats = s->stats;
+    f.W = W; f.H = H; f.stream = (hipStream_t)hip_stream; f.max_depth = st->max_trace_depth;
+    if (timed_launch(s, f.P, f.max_depth, f.stream, nullptr, true)) { set_err(std::string("qd_frame_begin: ") + g_err); return -1; }
+    f.launched = true;
+    return 0;
+}
+
+namespace {
+int frame_fetch(qd_scene* s) {
+    FramePlan& f = s->frame;
+    if (!f.launched) return set_err("no frame in flight (qd_frame_begin first)");
+    if (f.fetched) return 0;
+    if (finish_launch(s, f.P, f.max_depth, f.stream, &f.ms)) { f = FramePlan(); return -1; }
+    HIP_TRY(hipMemcpy(s->stg.host_frame, f.P.rgb, (size_t)f.W * f.H * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    f.fetched = true;
+    return 0;
+}
+}  // namespace
+
+extern "C" int qd_frame_read_rect(qd_scene* s, int x0, int y0, int x1, int y1, float* rgb, size_t pitch) {
+    if (!s || !rgb) return set_err("qd_frame_read_rect: null argument");
+    if (frame_fetch(s)) { set_err(std::string("qd_frame_read_rect: ") + g_err); return -1; }
+    const FramePlan& f = s->frame;
+    if (x1 <= x0 || y1 <= y0 || x0 < 0 || y0 < 0 || x1 > f.W || y1 > f.H) return set_err("qd_frame_read_rect: bad rectangle");
+    const size_t rw = (size_t)(x1 - x0);
+    if (pitch < rw * 3) return set_err("qd_frame_read_rect: row pitch smaller than the rectangle");
+    const float* src = (const float*)s->stg.host_frame;
+    for (int y = y0; y < y1; ++y) memcpy(rgb + (size_t)(y - y0) * pitch, src + ((size_t)y * f.W + x0) * 3, rw * 3 * sizeof(float));
+    return 0;
+}
+
+extern "C" int qd_frame_end(qd_scene* s, qd_stats* stats) {
+    if (!s) return set_err("qd_frame_end: null scene");
+    if (frame_fetch(s)) { set_err(std::string("qd_frame_end: ") + g_err); return -1; }
+    if (stats) {
+        unsigned long long h[8];
+        HIP_TRY(hipMemcpy(h, s->stats, sizeof h, hipMemcpyDeviceToHost));
+        stats->rays = h[0]; stats->primary_rays = h[1]; stats->shadow_rays = h[2]; stats->depth_killed = h[3];
+        stats->kd_nodes_visited = h[4]; stats->tris_tested = h[5]; stats->mesh_queries = h[6];
+        stats->kernel_ms = s->frame.ms;
+    }
+    s->frame = FramePlan();
+    return 0;
+}
+
+
 namespace {
 #define TRY3(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); aa_free(s); return -1; } } while (0)
 
-void aa_free(qd_scene* s) {
-    AaPlan& a = s->aa;
-    for (void* p : {(void*)a.first, (void*)a.slot, (void*)a.list}) if (p) (void)hipFree(p);
-    a = AaPlan();
-}
+void aa_free(qd_scene* s) { s->aa = AaPlan(); }      // the plan's buffers are staging buffers of the scene handle: they stay
 
 // Step 1 of the AA pass: copy the first-pass frame (device, contiguous) into the handle, mark, list.
 int aa_begin(qd_scene* s, const qd_settings* st, const float* rgb_dev, uint32_t* n_listed) {
@@ -1603,12 +1715,11 @@ int aa_begin(qd_scene* s, const qd_settings* st, const float* rgb_dev, uint32_t*
     AaPlan& a = s->aa;
     const size_t npx = (size_t)W * H;
     uint32_t* d_count = nullptr;
-    TRY3(hipMalloc((void**)&a.first, npx * 3 * sizeof(float)));
-    TRY3(hipMalloc((void**)&a.slot, npx * sizeof(int32_t)));
-    TRY3(hipMalloc((void**)&a.list, (npx + 1) * sizeof(uint32_t)));        // last word: the count
+    if (stage(s, kStAaFirst, npx * 3 * sizeof(float), (void**)&a.first) || stage(s, kStAaSlot, npx * sizeof(int32_t), (void**)&a.slot) ||
+        stage(s, kStAaList, (npx + 1) * sizeof(uint32_t), (void**)&a.list)) { aa_free(s); return -1; }     // last word of the list: the count
     d_count = a.list + npx;
-    TRY3(hipMemcpy(a.first, rgb_dev, npx * 3 * sizeof(float), hipMemcpyDeviceToDevice));
-    TRY3(hipMemset(d_count, 0, sizeof(uint32_t)));
+    TRY3(hipMemcpyAsync(a.first, rgb_dev, npx * 3 * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+    TRY3(hipMemsetAsync(d_count, 0, sizeof(uint32_t), nullptr));
     TRY3(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
     const dim3 blk(64), grd((unsigned)(W + 63) / 64, (unsigned)H);
     hipLaunchKernelGGL(aa_mark_kernel, grd, blk, 0, nullptr, a.first, W, H, st->want_adaptive_aa, st->aa_threshold, a.slot, a.list, d_count);
@@ -1616,12 +1727,9 @@ int aa_begin(qd_scene* s, const qd_settings* st, const float* rgb_dev, uint32_t*
     if (a.n_list > 1) {
         uint32_t* sorted = nullptr; void* tmp = nullptr; size_t tmp_bytes = 0;
         TRY3(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, a.list, sorted, (int)a.n_list));
-        hipError_t e1 = hipMalloc((void**)&sorted, (size_t)a.n_list * sizeof(uint32_t));
-        hipError_t e2 = e1 == hipSuccess ? hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1) : e1;
-        hipError_t e3 = e2 == hipSuccess ? hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, a.list, sorted, (int)a.n_list) : e2;
-        if (e3 == hipSuccess) e3 = hipMemcpy(a.list, sorted, (size_t)a.n_list * sizeof(uint32_t), hipMemcpyDeviceToDevice);
-        if (sorted) (void)hipFree(sorted); if (tmp) (void)hipFree(tmp);
-        TRY3(e3);
+        if (stage(s, kStAaSorted, (size_t)a.n_list * sizeof(uint32_t), (void**)&sorted) || stage(s, kStAaTmp, tmp_bytes, &tmp)) { aa_free(s); return -1; }
+        TRY3(hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, a.list, sorted, (int)a.n_list));
+        TRY3(hipMemcpyAsync(a.list, sorted, (size_t)a.n_list * sizeof(uint32_t), hipMemcpyDeviceToDevice, nullptr));
         hipLaunchKernelGGL(aa_slot_kernel, dim3((a.n_list + 255u) / 256u), dim3(256), 0, nullptr, a.list, a.n_list, W, a.slot);
         TRY3(hipGetLastError());
     }
@@ -1646,6 +1754,7 @@ int aa_trace(qd_scene* s, const qd_camera* cam, const qd_settings* st, uint32_t 
 }
 
 // Step 3: combine first-pass colour and taps, apply the bucket-ordered mark / replace rule, write the frame.
+constexpr int kAaBatch = 8;          // iterations of the rule enqueued between two looks at their "changed" flags
 int aa_end(qd_scene* s, const qd_settings* st, const float* taps_dev, float* rgb_dev) {
     AaPlan& a = s->aa;
     const int W = a.W, H = a.H;
@@ -1653,30 +1762,34 @@ int aa_end(qd_scene* s, const qd_settings* st, const float* taps_dev, float* rgb
     if (a.traced && !taps_dev) return set_err("qd_aa_end_device: taps missing");
     const size_t npx = (size_t)W * H;
     float *d_a = nullptr, *d_b = nullptr, *d_aa = nullptr; int* d_changed = nullptr;
-    auto cleanup = [&]() { for (void* p : {(void*)d_a, (void*)d_b, (void*)d_aa, (void*)d_changed}) if (p) (void)hipFree(p); aa_free(s); };
+    auto cleanup = [&]() { aa_free(s); };
 #define TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return -1; } } while (0)
-    TRY2(hipMalloc((void**)&d_a, npx * 3 * sizeof(float)));
-    TRY2(hipMalloc((void**)&d_b, npx * 3 * sizeof(float)));
-    TRY2(hipMalloc((void**)&d_changed, sizeof(int)));
+    if (stage(s, kStAaA, npx * 3 * sizeof(float), (void**)&d_a) || stage(s, kStAaB, npx * 3 * sizeof(float), (void**)&d_b) ||
+        stage(s, kStAaFlags, kAaBatch * sizeof(int), (void**)&d_changed)) { cleanup(); return -1; }
     if (a.traced) {
-        TRY2(hipMalloc((void**)&d_aa, (size_t)a.n_list * 3 * sizeof(float)));
+        if (stage(s, kStAaAa, (size_t)a.n_list * 3 * sizeof(float), (void**)&d_aa)) { cleanup(); return -1; }
         hipLaunchKernelGGL(aa_combine_kernel, dim3((a.n_list + 255u) / 256u), dim3(256), 0, nullptr, a.first, taps_dev, a.list, a.n_list, W, d_aa);
     }
-    // fixed point of the bucket-ordered rule; iteration k is exact for every pixel whose chain of earlier-bucket
-    // neighbours is shorter than k, so the bucket count bounds the loop
-    TRY2(hipMemcpy(d_a, a.first, npx * 3 * sizeof(float), hipMemcpyDeviceToDevice));
+    // Fixed point of the bucket-ordered rule; iteration k is exact for every pixel whose chain of earlier-bucket
+    // neighbours is shorter than k, so the bucket count bounds the loop.  kAaBatch iterations are enqueued back to back,
+    // each with a flag of its own, and the flags are read once: an iteration after the fixed point changes nothing, so
+    // running on to the end of the batch costs a few launches and saves a round trip per iteration.
+    TRY2(hipMemcpyAsync(d_a, a.first, npx * 3 * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
     float *cur = d_a, *next = d_b;
     const dim3 blk(64), grd((unsigned)(W + 63) / 64, (unsigned)H);
     const int max_iter = ((W - 1) / 48 + 1) * ((H - 1) / 48 + 1) + 2;
-    for (int iter = 0;; ++iter) {
+    bool settled = false;
+    for (int iter = 0; !settled; iter += kAaBatch) {
         if (iter > max_iter) { cleanup(); return set_err("qd_antialias: mark / replace rule did not settle"); }
-        TRY2(hipMemset(d_changed, 0, sizeof(int)));
-        hipLaunchKernelGGL(aa_resolve_kernel, grd, blk, 0, nullptr, a.first, cur, next, d_aa, a.slot, W, H, st->want_adaptive_aa, st->aa_threshold,
-                           st->show_aa, st->aa_debug_color[0], st->aa_debug_color[1], st->aa_debug_color[2], d_changed, s->error_flag);
-        int changed = 0;
-        TRY2(hipMemcpy(&changed, d_changed, sizeof changed, hipMemcpyDeviceToHost));
-        std::swap(cur, next);
-        if (!changed) break;
+        TRY2(hipMemsetAsync(d_changed, 0, kAaBatch * sizeof(int), nullptr));
+        for (int k = 0; k < kAaBatch; ++k) {
+            hipLaunchKernelGGL(aa_resolve_kernel, grd, blk, 0, nullptr, a.first, cur, next, d_aa, a.slot, W, H, st->want_adaptive_aa, st->aa_threshold,
+                               st->show_aa, st->aa_debug_color[0], st->aa_debug_color[1], st->aa_debug_color[2], d_changed + k, s->error_flag);
+            std::swap(cur, next);
+        }
+        int changed[kAaBatch];
+        TRY2(hipMemcpy(changed, d_changed, sizeof changed, hipMemcpyDeviceToHost));
+        for (int k = 0; k < kAaBatch; ++k) if (!changed[k]) settled = true;
     }
     int err_flag = 0;
     TRY2(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
@@ -1699,32 +1812,28 @@ int antialias_impl(qd_scene* s, const qd_camera* cam, const qd_settings* st, flo
     if (!rgb_dev && pitch < (size_t)W * 3) return set_err("qd_antialias: row pitch smaller than the frame");
     const size_t npx = (size_t)W * H;
     float *d_frame = nullptr, *d_taps = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    auto cleanup = [&]() {
-        if (d_frame) (void)hipFree(d_frame); if (d_taps) (void)hipFree(d_taps);
-        if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
-        aa_free(s);
-    };
+    Staging& g = s->stg;
+    auto cleanup = [&]() { aa_free(s); };
 #define TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); cleanup(); return -1; } } while (0)
     float* frame = rgb_dev;
     if (!rgb_dev) {
-        TRY2(hipMalloc((void**)&d_frame, npx * 3 * sizeof(float)));
+        if (stage(s, kStAaFrame, npx * 3 * sizeof(float), (void**)&d_frame)) return -1;
         TRY2(hipMemcpy2D(d_frame, (size_t)W * 3 * sizeof(float), rgb, pitch * sizeof(float), (size_t)W * 3 * sizeof(float), H, hipMemcpyHostToDevice));
         frame = d_frame;
     }
+    if (!g.e0) { TRY2(hipEventCreate(&g.e0)); TRY2(hipEventCreate(&g.e1)); }
     TRY2(hipMemsetAsync(s->stats, 0, 24 * sizeof(unsigned long long), nullptr));
     TRY2(hipMemsetAsync(s->stats + 16, 0xff, sizeof(unsigned long long), nullptr)); TRY2(hipMemsetAsync(s->stats + 19, 0xff, sizeof(unsigned long long), nullptr));
     uint32_t n_list = 0;
     if (aa_begin(s, st, frame, &n_list)) { cleanup(); return -1; }
     float ms = 0;
     if (n_list) {
-        TRY2(hipMalloc((void**)&d_taps, (size_t)n_list * 4 * 3 * sizeof(float)));
-        TRY2(hipEventCreate(&e0)); TRY2(hipEventCreate(&e1));
-        TRY2(hipEventRecord(e0, nullptr));
+        if (stage(s, kStAaTaps, (size_t)n_list * 4 * 3 * sizeof(float), (void**)&d_taps)) { cleanup(); return -1; }
+        TRY2(hipEventRecord(g.e0, nullptr));
         if (aa_trace(s, cam, st, 0, n_list, d_taps, s->stats, nullptr)) { cleanup(); return -1; }
-        TRY2(hipEventRecord(e1, nullptr));
-        TRY2(hipEventSynchronize(e1));
-        TRY2(hipEventElapsedTime(&ms, e0, e1));
+        TRY2(hipEventRecord(g.e1, nullptr));
+        TRY2(hipEventSynchronize(g.e1));
+        TRY2(hipEventElapsedTime(&ms, g.e0, g.e1));
         if (s->last_form == 1) {                // taps that outgrew the wavefront queues: once more in the one-kernel form
             int err_flag = 0;
             TRY2(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));

@@ -32,6 +32,9 @@ def lib():
         L.qd_scene_check.argtypes = [C.c_void_p]
         L.qd_render.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, P(abi.QdStats)]
+        L.qd_frame_begin.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_void_p]
+        L.qd_frame_read_rect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.qd_frame_end.argtypes = [C.c_void_p, P(abi.QdStats)]
         L.qd_antialias.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_void_p, C.c_size_t, P(abi.QdStats)]
         L.qd_antialias_device.argtypes = [C.c_void_p, P(abi.QdCamera), P(abi.QdSettings), C.c_void_p, P(abi.QdStats)]
         L.qd_aa_begin_device.argtypes = [C.c_void_p, P(abi.QdSettings), C.c_void_p, P(C.c_uint32)]
@@ -174,21 +177,53 @@ class DeviceScene:
                 stats[k] += aa[k]
         return rgb, stats
 
-    def render_buckets(self, on_bucket=None, camera=None, settings=None):
+    def frame_begin(self, camera=None, settings=None, stream=None):
+        """Enqueue the whole first pass of the frame (qd_frame_begin); rectangles are then read with frame_read_rect."""
+        st = settings if settings is not None else self.host_scene.settings
+        cam = camera if camera is not None else self.host_scene.camera
+        _check(lib().qd_frame_begin(self._h, C.byref(cam), C.byref(st), C.c_void_p(stream or 0)), "qd_frame_begin")
+
+    def frame_read_rect(self, x0, y0, x1, y1, out=None):
+        """Rectangle [x0,x1) x [y0,y1) of the frame begun last, as float32[h, w, 3] (`out`: a view to fill, last axis contiguous)."""
+        w, h = x1 - x0, y1 - y0
+        if out is None:
+            out = np.empty((h, w, 3), np.float32)
+        if out.dtype != np.float32 or out.shape != (h, w, 3) or out.strides[2] != 4 or out.strides[1] != 12 or out.strides[0] % 4:
+            raise DeviceError("frame_read_rect: out must be float32[h, w, 3] with contiguous pixels")
+        _check(lib().qd_frame_read_rect(self._h, x0, y0, x1, y1, out.ctypes.data, out.strides[0] // 4), "qd_frame_read_rect")
+        return out
+
+    def frame_end(self):
+        stats = abi.QdStats()
+        _check(lib().qd_frame_end(self._h, C.byref(stats)), "qd_frame_end")
+        return stats.as_dict()
+
+    def render_buckets(self, on_bucket=None, camera=None, settings=None, launch_per_bucket=False):
         """SimpleRender (src/main.cpp:85-104): the frame bucket by bucket in GetBucketList order (src/sdl.cpp:253-276);
         after each bucket `on_bucket((x0, y0, x1, y1), frame)` plays DisplayVFBRect -- returning False stops the render
         there, as the reference does when the user closes the window (src/main.cpp:99-100), and the call returns
-        (frame, False) with the buckets finished so far."""
+        (frame, False) with the buckets finished so far.  The frame is traced by ONE launch ahead of the loop
+        (qd_frame_begin) and the loop reads finished buckets; launch_per_bucket=True traces each bucket by a qd_render
+        call of its own instead (the reference's literal shape: a 48 x 48 launch leaves most of the GPU empty)."""
         from . import host
         st = settings if settings is not None else self.host_scene.settings
         W, H = st.frame_width, st.frame_height
         frame = np.zeros((H, W, 3), np.float32)
-        for (x0, y0, x1, y1) in host.bucket_list(W, H):
-            rgb, _, _ = self.render(int(x0), int(y0), int(x1), int(y1), camera=camera, settings=settings)
-            frame[y0:y1, x0:x1] = rgb
-            if on_bucket is not None and on_bucket((int(x0), int(y0), int(x1), int(y1)), frame) is False:
-                return frame, False
-        return frame, True
+        if not launch_per_bucket:
+            self.frame_begin(camera=camera, settings=settings)
+        try:
+            for (x0, y0, x1, y1) in host.bucket_list(W, H):
+                x0, y0, x1, y1 = int(x0), int(y0), int(x1), int(y1)
+                if launch_per_bucket:
+                    frame[y0:y1, x0:x1] = self.render(x0, y0, x1, y1, camera=camera, settings=settings)[0]
+                else:
+                    self.frame_read_rect(x0, y0, x1, y1, out=frame[y0:y1, x0:x1])
+                if on_bucket is not None and on_bucket((x0, y0, x1, y1), frame) is False:
+                    return frame, False
+            return frame, True
+        finally:
+            if not launch_per_bucket:
+                self.frame_end()
 
     def render_tiles_async(self, rgb_dev_ptr, tile, phase, stride, stats_dev_ptr=None, stream=None,
                            camera=None, settings=None):

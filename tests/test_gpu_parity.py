@@ -251,24 +251,73 @@ def test_pack_rgb32_kernel_matches_to_rgb32():
             assert np.array_equal(out.cpu().numpy().view(np.uint32), oracle.to_rgb32(img, srgb=srgb, shifts=shifts)), (srgb, shifts)
 
 
-def test_bucket_by_bucket_render_and_cancel(load_scene):
+@pytest.mark.parametrize("launch_per_bucket", [False, True])
+def test_bucket_by_bucket_render_and_cancel(load_scene, launch_per_bucket):
     """SimpleRender's loop (src/main.cpp:85-104): buckets in GetBucketList order, a display hook per bucket whose False
-    stops the render; the finished frame equals the single-rectangle frame."""
+    stops the render; the finished frame equals the single-rectangle frame.  Both shapes of the loop: one launch ahead of
+    it and rectangle reads (qd_frame_begin / qd_frame_read_rect), or a qd_render call per bucket."""
     s = load_scene("kdtree_teapot_lowres_env.qdmg")
     old = _aa_settings(s, want_aa=0)
     ds = device.DeviceScene(s)
     try:
         full, _, _ = ds.render()
         seen = []
-        frame, done = ds.render_buckets(lambda r, f: seen.append(r))
+        frame, done = ds.render_buckets(lambda r, f: seen.append(r), launch_per_bucket=launch_per_bucket)
         assert done and seen == [tuple(int(v) for v in b) for b in host.bucket_list(s.settings.frame_width, s.settings.frame_height)]
         assert np.abs(frame - full).max() <= SUM_ORDER_TOL
-        part, done = ds.render_buckets(lambda r, f: len(seen) < 0 or r != seen[2])
+        part, done = ds.render_buckets(lambda r, f: len(seen) < 0 or r != seen[2], launch_per_bucket=launch_per_bucket)
         assert not done
         x0, y0, x1, y1 = seen[2]
         assert np.abs(part[y0:y1, x0:x1] - full[y0:y1, x0:x1]).max() <= SUM_ORDER_TOL
         x0, y0, x1, y1 = seen[3]
         assert not part[y0:y1, x0:x1].any()                     # never started
+    finally:
+        ds.close()
+        _aa_settings(s, **old)
+
+
+def test_frame_api_errors_and_bucket_loop_cost(load_scene):
+    """qd_frame_*: a read without a frame in flight and a rectangle outside the frame are refused; the bucket loop over a
+    frame begun ahead costs at most 1.3x the single-rectangle call (kdtree_fixed, 475 buckets; best of three each)."""
+    import time
+    s = load_scene("kdtree_fixed.qdmg")
+    old = _aa_settings(s, want_aa=0)
+    ds = device.DeviceScene(s)
+    try:
+        with pytest.raises(device.DeviceError, match="no frame in flight"):
+            ds.frame_read_rect(0, 0, 8, 8)
+        W, H = s.settings.frame_width, s.settings.frame_height
+        ds.frame_begin()
+        with pytest.raises(device.DeviceError, match="bad rectangle"):
+            ds.frame_read_rect(0, 0, W + 1, 8)
+        st = ds.frame_end()
+        assert st["primary_rays"] == W * H
+        import ctypes as C
+        L, cam, stt = device.lib(), s.camera, s.settings
+        buckets = [tuple(int(v) for v in b) for b in host.bucket_list(W, H)]
+        full = np.zeros((H, W, 3), np.float32)
+        frame = np.zeros((H, W, 3), np.float32)
+        stats = device.abi.QdStats()
+
+        def single_call():
+            assert L.qd_render(ds._h, C.byref(cam), C.byref(stt), 0, 0, W, H, full.ctypes.data, W * 3, None, None, None, C.byref(stats)) == 0
+
+        def bucket_loop():                                       # the loop of INTEGRATION.md, through the C ABI
+            assert L.qd_frame_begin(ds._h, C.byref(cam), C.byref(stt), None) == 0
+            base = frame.ctypes.data
+            for (x0, y0, x1, y1) in buckets:
+                assert L.qd_frame_read_rect(ds._h, x0, y0, x1, y1, C.c_void_p(base + (y0 * W + x0) * 12), W * 3) == 0
+            assert L.qd_frame_end(ds._h, C.byref(stats)) == 0
+
+        for _ in range(3):                                       # both forms of the schedule measured, staging allocated
+            single_call(); bucket_loop()
+        single, loop = [], []
+        for _ in range(3):
+            t0 = time.perf_counter(); single_call(); single.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); bucket_loop(); loop.append(time.perf_counter() - t0)
+            assert np.abs(frame - full).max() <= SUM_ORDER_TOL
+        print(f"single rectangle {min(single) * 1e3:.1f} ms, bucket loop {min(loop) * 1e3:.1f} ms")
+        assert min(loop) <= 1.3 * min(single), (single, loop)
     finally:
         ds.close()
         _aa_settings(s, **old)
