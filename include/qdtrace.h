@@ -221,6 +221,14 @@ typedef struct qd_stats {
     double   kernel_ms;       /* device time of the trace kernel(s), HIP events         */
 } qd_stats;
 
+/* Threads.  qd_last_error() is per thread.  Every call that takes a qd_scene* locks the handle for its duration, so calls
+ * on one handle from several threads are safe and serialise on the host (the asynchronous ones only enqueue, the GPU work
+ * of different streams still overlaps); different handles do not contend.  What a handle holds ONE of -- the AA plan
+ * (qd_aa_begin_device .. qd_aa_end_device), the frame of qd_frame_begin, the staging of the synchronous calls -- belongs
+ * to one logical caller at a time.  Each working set (stream) has its own device error word: a synchronous call clears
+ * and reads only its own, qd_scene_check reads them all.  qd_init and the qd_set_* switches are process-wide and are
+ * meant to be called before the threads start. */
+
 /* Replaces: process start-up (the reference has none for a device). 0 on success, <0 on error.
  * device = HIP device ordinal to bind this process to (one process per GPU). */
 int qd_init(int device);

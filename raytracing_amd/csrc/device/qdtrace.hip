@@ -924,8 +924,10 @@ int set_err(const std::string& m) { g_err = m; return -1; }
 // rendered on different streams overlap on the GPU: the tail of one frame (few waves walking the last generations of
 // their ray trees) runs beside the start of the next.  Launches on one stream share a set and serialise as before.
 constexpr int kMaxWorkSets = 8;              // streams beyond the process's hardware queues (GPU_MAX_HW_QUEUES, 4 by default) share one and serialise
+constexpr int kErrAa = 8, kErrNoAlloc = 9, kErrFlags = 10;     // error words beyond the kMaxWorkSets per-set ones
 struct WorkSet {
     bool bound = false;
+    int last_form = 0;                       // scheduling form of the set's last launch
     hipStream_t stream = nullptr;
     uint32_t stack_cap = 0;
     uint64_t* stack = nullptr;
@@ -990,7 +992,8 @@ struct qd_scene {
     WorkSet sets[kMaxWorkSets];
     uint64_t use_clock = 0;
     unsigned long long* stats = nullptr; // 8 counters
-    int* error_flag = nullptr;
+    int* error_flag = nullptr;           // kErrFlags device words: one per working set (its launches raise it), the AA rule's, the no-alloc call's
+    std::mutex mu;                       // the handle's host state (working sets, plans, staging): one caller at a time
     uint32_t spawn0 = 1, spawn1 = 1;     // tasks queued per hit at depth 0 / deeper
     int geom_mask = 7;                   // kGeomHf | kGeomCsg | kGeomPrim | kGeomCsgDeep as present in the scene: selects the kernel copy
     bool rich = true;                    // bitmap / Mandelbrot / procedural textures or bump maps present
@@ -1108,7 +1111,7 @@ int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hip
     }
     P.wf_ray[0] = w->wf_ray[0]; P.wf_ray[1] = w->wf_ray[1]; P.wf_res = w->wf_res; P.wf_ctl = w->wf_ctl; P.wf_deep = w->wf_deep;
     P.wf_cap = (uint32_t)w->wf_cap;
-    P.error_flag = s->error_flag;
+    P.error_flag = s->error_flag + (w - s->sets);
     HIP_TRY(hipMemsetAsync(w->wf_ctl, 0, (size_t)(max_depth + 3) * kWfGenWords * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));
     using ShadeK = void (*)(const DScene, const Params, int);
@@ -1178,13 +1181,13 @@ int launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream) {
     if (rc) return rc;
     HIP_TRY(hipEventRecord(w->t1, stream));
     w->timed_form = form; w->timed_slots = (uint64_t)P.n_units * kUnitPx;
-    s->last_form = form;
+    s->last_form = form; w->last_form = form;
     return 0;
 }
 
 int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hipStream_t stream) {
     P.stack = w->stack; P.stack_cap = w->stack_cap; P.n_lanes = s->n_lanes;
-    P.error_flag = s->error_flag;
+    P.error_flag = s->error_flag + (w - s->sets);
     P.list_cap = w->list_cap;
     HIP_TRY(hipMemsetAsync(w->queue_ctr, 0, (size_t)kPasses * kPassWords * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));       // the kernel adds colours into it
@@ -1241,10 +1244,12 @@ int finish_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream
 int timed_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream, float* ms, bool begin_only = false) {
     Staging& g = s->stg;
     if (!g.e0) { HIP_TRY(hipEventCreate(&g.e0)); HIP_TRY(hipEventCreate(&g.e1)); }
+    WorkSet* w = nullptr;
+    if (acquire_set(s, stream, max_depth, &w)) return -1;            // the set launch() is about to use: its error word
     HIP_TRY(hipMemsetAsync(s->stats, 0, 24 * sizeof(unsigned long long), stream));
     HIP_TRY(hipMemsetAsync(s->stats + 16, 0xff, sizeof(unsigned long long), stream));
     HIP_TRY(hipMemsetAsync(s->stats + 19, 0xff, sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(s->error_flag, 0, sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(s->error_flag + (w - s->sets), 0, sizeof(int), stream));
     HIP_TRY(hipEventRecord(g.e0, stream));
     if (launch(s, P, max_depth, stream)) return -1;
     HIP_TRY(hipEventRecord(g.e1, stream));
@@ -1254,9 +1259,13 @@ int finish_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream
     Staging& g = s->stg;
     HIP_TRY(hipEventSynchronize(g.e1));
     if (ms) HIP_TRY(hipEventElapsedTime(ms, g.e0, g.e1));
+    WorkSet* w = nullptr;
+    for (auto& c : s->sets) if (c.bound && c.stream == stream) { w = &c; break; }
+    if (!w) return set_err("the stream's working set was taken over before the call finished (more than 8 streams on one scene)");
+    int* flag = s->error_flag + (w - s->sets);
     int err_flag = 0;
-    HIP_TRY(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (err_flag == 1 && s->last_form == 1) {
+    HIP_TRY(hipMemcpy(&err_flag, flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (err_flag == 1 && w->last_form == 1) {
         s->wavefront_overflowed = true;
         const int saved_pipeline = g_pipeline;
         g_pipeline = 0;
@@ -1265,8 +1274,8 @@ int finish_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream
         return rc;
     }
     if (err_flag) {
-        (void)hipMemset(s->error_flag, 0, sizeof(int));
-        return set_err(err_flag == 2 ? "marked pixel outside the traced set" : "ray queue overflow on device");
+        (void)hipMemset(flag, 0, sizeof(int));
+        return set_err("ray queue overflow on device");
     }
     return 0;
 }
@@ -1549,8 +1558,8 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
 #endif
     s->n_lanes = (uint32_t)(g_num_cu > 0 ? g_num_cu : 256) * kWavesPerCU * 64u;
     if (!rc && hipMalloc((void**)&s->stats, (24 + 6 * 4096) * sizeof(unsigned long long)) != hipSuccess) rc = set_err("hipMalloc(stats) failed");
-    if (!rc && hipMalloc((void**)&s->error_flag, sizeof(int)) != hipSuccess) rc = set_err("hipMalloc(error flag) failed");
-    if (!rc && hipMemset(s->error_flag, 0, sizeof(int)) != hipSuccess) rc = set_err("hipMemset failed");
+    if (!rc && hipMalloc((void**)&s->error_flag, kErrFlags * sizeof(int)) != hipSuccess) rc = set_err("hipMalloc(error flags) failed");
+    if (!rc && hipMemset(s->error_flag, 0, kErrFlags * sizeof(int)) != hipSuccess) rc = set_err("hipMemset failed");
     if (!rc) {                                   // working set of the default stream, so that a first render allocates nothing
         WorkSet* w = nullptr;
         rc = acquire_set(s, nullptr, desc->settings.max_trace_depth, &w);
@@ -1576,6 +1585,7 @@ extern "C" void qd_scene_destroy(qd_scene* s) {
 extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* st, int x0, int y0, int x1, int y1,
                          float* rgb, size_t pitch, int32_t* hit_node, int32_t* hit_tri, double* hit_dist, qd_stats* stats) {
     if (!s || !cam || !st || !rgb) return set_err("qd_render: null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
     if (x1 <= x0 || y1 <= y0 || x0 < 0 || y0 < 0 || x1 > st->frame_width || y1 > st->frame_height) return set_err("qd_render: bad rectangle");
     if ((hit_node || hit_tri || hit_dist) && !(hit_node && hit_tri && hit_dist)) return set_err("qd_render: hit outputs must be all set or all NULL");
     const int rw = x1 - x0, rh = y1 - y0;
@@ -1639,6 +1649,7 @@ extern "C" int qd_render(qd_scene* s, const qd_camera* cam, const qd_settings* s
 // is then a copy of rows on the host).
 extern "C" int qd_frame_begin(qd_scene* s, const qd_camera* cam, const qd_settings* st, void* hip_stream) {
     if (!s || !cam || !st) return set_err("qd_frame_begin: null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
     const int W = st->frame_width, H = st->frame_height;
     if (W <= 0 || H <= 0) return set_err("qd_frame_begin: frame size out of range");
     FramePlan& f = s->frame;
@@ -1677,6 +1688,7 @@ int frame_fetch(qd_scene* s) {
 
 extern "C" int qd_frame_read_rect(qd_scene* s, int x0, int y0, int x1, int y1, float* rgb, size_t pitch) {
     if (!s || !rgb) return set_err("qd_frame_read_rect: null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
     if (frame_fetch(s)) { set_err(std::string("qd_frame_read_rect: ") + g_err); return -1; }
     const FramePlan& f = s->frame;
     if (x1 <= x0 || y1 <= y0 || x0 < 0 || y0 < 0 || x1 > f.W || y1 > f.H) return set_err("qd_frame_read_rect: bad rectangle");
@@ -1689,6 +1701,7 @@ extern "C" int qd_frame_read_rect(qd_scene* s, int x0, int y0, int x1, int y1, f
 
 extern "C" int qd_frame_end(qd_scene* s, qd_stats* stats) {
     if (!s) return set_err("qd_frame_end: null scene");
+    std::lock_guard<std::mutex> lock(s->mu);
     if (frame_fetch(s)) { set_err(std::string("qd_frame_end: ") + g_err); return -1; }
     if (stats) {
         unsigned long long h[8];
@@ -1720,7 +1733,7 @@ int aa_begin(qd_scene* s, const qd_settings* st, const float* rgb_dev, uint32_t*
     d_count = a.list + npx;
     TRY3(hipMemcpyAsync(a.first, rgb_dev, npx * 3 * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
     TRY3(hipMemsetAsync(d_count, 0, sizeof(uint32_t), nullptr));
-    TRY3(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
+    TRY3(hipMemsetAsync(s->error_flag + kErrAa, 0, sizeof(int), nullptr));
     const dim3 blk(64), grd((unsigned)(W + 63) / 64, (unsigned)H);
     hipLaunchKernelGGL(aa_mark_kernel, grd, blk, 0, nullptr, a.first, W, H, st->want_adaptive_aa, st->aa_threshold, a.slot, a.list, d_count);
     TRY3(hipMemcpy(&a.n_list, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1784,19 +1797,21 @@ int aa_end(qd_scene* s, const qd_settings* st, const float* taps_dev, float* rgb
         TRY2(hipMemsetAsync(d_changed, 0, kAaBatch * sizeof(int), nullptr));
         for (int k = 0; k < kAaBatch; ++k) {
             hipLaunchKernelGGL(aa_resolve_kernel, grd, blk, 0, nullptr, a.first, cur, next, d_aa, a.slot, W, H, st->want_adaptive_aa, st->aa_threshold,
-                               st->show_aa, st->aa_debug_color[0], st->aa_debug_color[1], st->aa_debug_color[2], d_changed + k, s->error_flag);
+                               st->show_aa, st->aa_debug_color[0], st->aa_debug_color[1], st->aa_debug_color[2], d_changed + k, s->error_flag + kErrAa);
             std::swap(cur, next);
         }
         int changed[kAaBatch];
         TRY2(hipMemcpy(changed, d_changed, sizeof changed, hipMemcpyDeviceToHost));
         for (int k = 0; k < kAaBatch; ++k) if (!changed[k]) settled = true;
     }
-    int err_flag = 0;
-    TRY2(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (err_flag) {
-        (void)hipMemset(s->error_flag, 0, sizeof(int));
+    int flags[kErrFlags];                                  // the rule's own word, and those of the sets that traced the taps
+    TRY2(hipMemcpy(flags, s->error_flag, sizeof flags, hipMemcpyDeviceToHost));
+    bool overflow = false;
+    for (int i = 0; i < kMaxWorkSets; ++i) overflow |= flags[i] != 0;
+    if (flags[kErrAa] || overflow) {
+        (void)hipMemset(s->error_flag, 0, sizeof flags);
         cleanup();
-        return set_err(err_flag == 2 ? "qd_antialias: marked pixel outside the traced set" : "qd_antialias: ray queue overflow on device");
+        return set_err(flags[kErrAa] ? "qd_antialias: marked pixel outside the traced set" : "qd_antialias: ray queue overflow on device");
     }
     TRY2(hipMemcpy(rgb_dev, cur, npx * 3 * sizeof(float), hipMemcpyDeviceToDevice));
     cleanup();
@@ -1807,6 +1822,7 @@ int aa_end(qd_scene* s, const qd_settings* st, const float* taps_dev, float* rgb
 // rgb: host buffer with `pitch`, or (rgb_dev) a contiguous W x H x 3 device buffer; in place either way
 int antialias_impl(qd_scene* s, const qd_camera* cam, const qd_settings* st, float* rgb, size_t pitch, float* rgb_dev, qd_stats* stats) {
     if (!s || !cam || !st || !(rgb || rgb_dev)) return set_err("qd_antialias: null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
     const int W = st->frame_width, H = st->frame_height;
     if (W <= 0 || H <= 0 || W > 65535 || H > 65535) return set_err("qd_antialias: frame size out of range");
     if (!rgb_dev && pitch < (size_t)W * 3) return set_err("qd_antialias: row pitch smaller than the frame");
@@ -1829,19 +1845,23 @@ int antialias_impl(qd_scene* s, const qd_camera* cam, const qd_settings* st, flo
     float ms = 0;
     if (n_list) {
         if (stage(s, kStAaTaps, (size_t)n_list * 4 * 3 * sizeof(float), (void**)&d_taps)) { cleanup(); return -1; }
+        WorkSet* w0 = nullptr;
+        if (acquire_set(s, nullptr, st->max_trace_depth, &w0)) { cleanup(); return -1; }
+        int* const flag = s->error_flag + (w0 - s->sets);          // the error word of the set these launches use
+        TRY2(hipMemsetAsync(flag, 0, sizeof(int), nullptr));
         TRY2(hipEventRecord(g.e0, nullptr));
         if (aa_trace(s, cam, st, 0, n_list, d_taps, s->stats, nullptr)) { cleanup(); return -1; }
         TRY2(hipEventRecord(g.e1, nullptr));
         TRY2(hipEventSynchronize(g.e1));
         TRY2(hipEventElapsedTime(&ms, g.e0, g.e1));
-        if (s->last_form == 1) {                // taps that outgrew the wavefront queues: once more in the one-kernel form
+        if (w0->last_form == 1) {               // taps that outgrew the wavefront queues: once more in the one-kernel form
             int err_flag = 0;
-            TRY2(hipMemcpy(&err_flag, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
+            TRY2(hipMemcpy(&err_flag, flag, sizeof(int), hipMemcpyDeviceToHost));
             if (err_flag == 1) {
                 s->wavefront_overflowed = true;
                 const int saved_pipeline = g_pipeline;
                 TRY2(hipMemsetAsync(s->stats, 0, 16 * sizeof(unsigned long long), nullptr));
-                TRY2(hipMemsetAsync(s->error_flag, 0, sizeof(int), nullptr));
+                TRY2(hipMemsetAsync(flag, 0, sizeof(int), nullptr));
                 g_pipeline = 0;
                 const int rc2 = aa_trace(s, cam, st, 0, n_list, d_taps, s->stats, nullptr);
                 g_pipeline = saved_pipeline;
@@ -1868,18 +1888,21 @@ int antialias_impl(qd_scene* s, const qd_camera* cam, const qd_settings* st, flo
 
 extern "C" int qd_aa_begin_device(qd_scene* s, const qd_settings* st, const float* rgb_dev, uint32_t* n_listed) {
     if (!s || !st || !rgb_dev) return set_err("qd_aa_begin_device: null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
     return aa_begin(s, st, rgb_dev, n_listed);
 }
 
 extern "C" int qd_aa_trace_part_async(qd_scene* s, const qd_camera* cam, const qd_settings* st, uint32_t first_pixel, uint32_t n_pixels,
                                       float* taps_dev, qd_stats* stats_dev, void* hip_stream) {
     if (!s || !cam || !st || (!taps_dev && n_pixels)) return set_err("qd_aa_trace_part_async: null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
     if (stats_dev) HIP_TRY(hipMemsetAsync(stats_dev, 0, sizeof(qd_stats), (hipStream_t)hip_stream));
     return aa_trace(s, cam, st, first_pixel, n_pixels, taps_dev, (unsigned long long*)stats_dev, (hipStream_t)hip_stream);
 }
 
 extern "C" int qd_aa_end_device(qd_scene* s, const qd_settings* st, const float* taps_dev, float* rgb_dev) {
     if (!s || !st) return set_err("qd_aa_end_device: null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
     if (!rgb_dev) { HIP_TRY(hipDeviceSynchronize()); aa_free(s); return 0; }     // a rank that only traced a slice drops its plan
     return aa_end(s, st, taps_dev, rgb_dev);
 }
@@ -1897,6 +1920,7 @@ extern "C" int qd_antialias_device(qd_scene* s, const qd_camera* cam, const qd_s
 extern "C" int qd_render_tiles_async(qd_scene* s, const qd_camera* cam, const qd_settings* st, int tile, int tile_phase,
                                      int tile_stride, float* rgb_dev, qd_stats* stats_dev, void* hip_stream) {
     if (!s || !cam || !st || !rgb_dev) return set_err("qd_render_tiles_async: null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
     if (tile < 8 || tile % 8 || tile_stride < 1 || tile_phase < 0 || tile_phase >= tile_stride) return set_err("qd_render_tiles_async: bad tiling");
     hipStream_t stream = (hipStream_t)hip_stream;
     Params P; fill_common(P, cam, st);
@@ -1919,6 +1943,7 @@ extern "C" int qd_render_tiles_async(qd_scene* s, const qd_camera* cam, const qd
 extern "C" int qd_render_tiles_noalloc_async(qd_scene* s, const qd_camera* cam, const qd_settings* st, int tile, int tile_phase,
                                              int tile_stride, float* rgb_dev, qd_stats* stats_dev, void* hip_stream) {
     if (!s || !cam || !st || !rgb_dev) return set_err("qd_render_tiles_noalloc_async: null argument");
+    std::lock_guard<std::mutex> lock(s->mu);
     if (tile < 8 || tile % 8 || tile_stride < 1 || tile_phase < 0 || tile_phase >= tile_stride) return set_err("qd_render_tiles_noalloc_async: bad tiling");
     if (g_device < 0 || g_device >= kMaxDevices || !g_scratch_ptr[g_device]) return set_err("qd_render_tiles_noalloc_async: qd_init has not bound this device's scratch");
     unsigned char* const ptr = g_scratch_ptr[g_device];
@@ -1946,7 +1971,7 @@ extern "C" int qd_render_tiles_noalloc_async(qd_scene* s, const qd_camera* cam, 
     if (P.n_units == 0) return 0;
     uint32_t* ctl = (uint32_t*)ptr;
     P.stack = (uint64_t*)(ptr + kScratchCtlBytes); P.stack_cap = (uint32_t)cap64; P.n_lanes = waves * 64u;
-    P.error_flag = s->error_flag;
+    P.error_flag = s->error_flag + kErrNoAlloc;
     P.queue_ctr = ctl; P.out_count = ctl + 8 * kCtlStride; P.pass_done = ctl + 16 * kCtlStride;
     P.source = 0; P.grace = 0xffffffffu;                    // one pass that runs to the end: no task lists
     P.in_count = nullptr; P.in_list = nullptr; P.out_list = nullptr; P.list_cap = 0;
@@ -1969,6 +1994,7 @@ extern "C" int qd_render_tiles_noalloc_async(qd_scene* s, const qd_camera* cam, 
 
 extern "C" int qd_scene_bind_stream(qd_scene* s, int max_trace_depth, void* hip_stream) {
     if (!s || max_trace_depth < 0) return set_err("qd_scene_bind_stream: bad argument");
+    std::lock_guard<std::mutex> lock(s->mu);
     WorkSet* w = nullptr;
     return acquire_set(s, (hipStream_t)hip_stream, (uint32_t)max_trace_depth, &w);
 }
@@ -2002,11 +2028,14 @@ extern "C" int qd_pack_rgb32_async(const float* rgb_dev, size_t row_pitch_floats
 // Device error flag of the last asynchronous launches on this scene (ray queue overflow): 0 = fine.
 extern "C" int qd_scene_check(qd_scene* s) {
     if (!s) return set_err("qd_scene_check: null scene");
-    int f = 0;
-    HIP_TRY(hipMemcpy(&f, s->error_flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (f) {
-        (void)hipMemset(s->error_flag, 0, sizeof(int));
-        if (s->last_form == 1) {       // a generation outgrew the wavefront queues: this scene stays on the one-kernel form from here on
+    std::lock_guard<std::mutex> lock(s->mu);
+    int f[kErrFlags];
+    HIP_TRY(hipMemcpy(f, s->error_flag, sizeof f, hipMemcpyDeviceToHost));
+    bool any = false, wavefront = false;
+    for (int i = 0; i < kErrFlags; ++i) if (f[i]) { any = true; if (i < kMaxWorkSets && s->sets[i].last_form == 1) wavefront = true; }
+    if (any) {
+        (void)hipMemset(s->error_flag, 0, sizeof f);
+        if (wavefront) {               // a generation outgrew the wavefront queues: this scene stays on the one-kernel form from here on
             s->wavefront_overflowed = true;
             return set_err("ray queue overflow on device (wavefront form; the scene's next frames use the one-kernel form, whose queues cannot overflow)");
         }
