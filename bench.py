@@ -131,9 +131,16 @@ def main():
     if args.kd_refine:
         ml, sc = args.kd_refine.split(",")
         device.set_kd_refine(int(ml), float(sc))
+    device.init(local)
+    from raytracing_amd import host
+    host.prep_on_device(True)      # heightfield tables / bump-map differentiation of the scene by the device kernels (same bits as the CPU code)
+    t_setup = time.perf_counter()
     scene, workload = build_scene(args)
+    t_host_scene = time.perf_counter() - t_setup
+    t_setup = time.perf_counter()
     fr = renderer.FrameRenderer(scene, tile=args.tile, rank=rank, world=world, local_device=local,
                                 frames_in_flight=args.frames_in_flight)
+    t_device_scene = time.perf_counter() - t_setup     # qd_scene_create: upload + device KD tree build, untimed set-up
     W, H = fr.W, fr.H
 
     def barrier():
@@ -212,7 +219,8 @@ def main():
             "config": {"workload": workload, "width": W, "height": H, "rays_per_frame": int(rays_frame),
                        "primary_rays": int(rays_local[1].item()), "shadow_rays": int(rays_local[2].item()),
                        "parallelism": f"tiles{args.tile}x{args.tile} interleaved over {world} rank(s), RCCL gather to rank 0",
-                       "frames_in_flight": args.frames_in_flight, "schedule": fr.dscene.schedule_info()},
+                       "frames_in_flight": args.frames_in_flight, "schedule": fr.dscene.schedule_info(),
+                       "setup_s": {"host_scene": round(t_host_scene, 2), "device_scene": round(t_device_scene, 2), **{k: round(v, 2) for k, v in fr.dscene.setup_info().items()}}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "trace_kernel" if form == 0 else "wf_walk_kernel + wf_shade_kernel", "kernel_ms": kernel_ms,

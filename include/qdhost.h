@@ -58,6 +58,21 @@ void   qdh_free(void* p);
  * 16-double record, 52 doubles out; checked bit for bit against the reference's own object code (tests/golden/ref/). */
 void qdh_math_probe(const double in[16], double out[52]);
 
+/* Scene preparation on the device.  The table passes of BeginRender -- heightfield blur / max-heights /
+ * normals / high map (src/heightfield.cpp:102-214, 260-290) and Bitmap::Differentiate (src/bitmap.cpp:312-326) -- run on
+ * the CPU by default.  A caller that has the device library hands its three entry points over (they have exactly these
+ * signatures: qd_prep_heightfield, qd_prep_highmap, qd_prep_differentiate in qdtrace.h) and scenes loaded afterwards
+ * get their tables from HIP kernels; the tables are bit-identical either way.  A hook that returns non-zero fails the
+ * load.  NULL (or a NULL member) = CPU code.  Process-wide; set it before loading scenes. */
+typedef struct qdh_prep_hooks {
+    int (*heightfield)(uint32_t width, uint32_t height, const float* rgb, const float* gauss, int r,
+                       float* heights, float* maxheights, double* normals);
+    int (*highmap)(uint32_t width, uint32_t height, const float* heights, int max_k, float* highmap);
+    int (*differentiate)(uint32_t width, uint32_t height, float* rgb);
+} qdh_prep_hooks;
+void qdh_set_prep_hooks(const qdh_prep_hooks* hooks);
+int qdh_prep_hook_calls(void);      /* table passes that went through a hook so far (for tests) */
+
 void qdh_free_scene(qdh_scene* s);
 const char* qdh_last_error(void);
 

@@ -369,6 +369,25 @@ int qd_comm_broadcast_async(qd_comm* comm, float* buf_dev, size_t count, void* h
 int qd_gather_frame_async(qd_comm* comm, const float* shard_dev, float* gathered_dev, float* frame_dev,
                           int width, int height, int tile, void* hip_stream);
 
+/* --------------------------------------------------------------------------
+ * Scene preparation on the device.  Host pointers in, host pointers out (once per scene; the kernels
+ * are in csrc/device/prep.h); every table is bit-identical to the one libqdhost computes on the CPU
+ * (tests/test_gpu_parity.py::test_device_prep_tables_equal_the_host_tables).  libqdhost calls them when they are given to
+ * it with qdh_set_prep_hooks (include/qdhost.h).
+ *
+ * qd_prep_heightfield  Replaces: Heightfield::FillProperties' grey / gaussian blur pass and PopulateMaxHeights /
+ *   PopulateNormals (src/heightfield.cpp:102-125, 170-214).  rgb: width*height*3 floats of the loaded bitmap; gauss: r*r
+ *   floats, gauss[y*r + x] = exp(-(x^2+y^2)/(2 blur^2)) / (2 pi blur^2) as floats, r = min(128, nearestInt(3 blur)), or
+ *   r = 0 for no blur (the weights need libm's exp and come from the caller).  Out: heights, maxheights (width*height
+ *   floats each), normals (3 doubles per cell).
+ * qd_prep_highmap      Replaces: Heightfield::BuildHighMap (src/heightfield.cpp:260-290).  highmap: 16 floats per cell,
+ *   levels 0 .. max_k-1 filled, the rest zero.
+ * qd_prep_differentiate Replaces: Bitmap::Differentiate (src/bitmap.cpp:312-326), in place on width*height*3 floats. */
+int qd_prep_heightfield(uint32_t width, uint32_t height, const float* rgb, const float* gauss, int r,
+                        float* heights, float* maxheights, double* normals);
+int qd_prep_highmap(uint32_t width, uint32_t height, const float* heights, int max_k, float* highmap);
+int qd_prep_differentiate(uint32_t width, uint32_t height, float* rgb);
+
 /* Replaces: Color::toRGB32 / ConvertTo8Bit (src/color.cpp:16-24, src/utils.h:22,34):
  * clamp, floor(x*255+0.5); rgb float image (device) -> packed 8-bit B,G,R rows
  * bottom-up as Bitmap::SaveBMP writes them (src/bitmap.cpp:209-217). */
@@ -425,6 +444,9 @@ int qd_set_kd_build(int mode);
 /* Size of the device tree of a scene (after refinement): nodes, leaf references, leaves, largest leaf.
  * Any pointer may be NULL.  The reference prints the same figures for its own tree at src/mesh.cpp:211-213. */
 int qd_scene_kd_info(const qd_scene* scene, uint64_t* nodes, uint64_t* leaf_refs, uint64_t* leaves, uint64_t* max_leaf);
+/* Where qd_scene_create spent its time (seconds): building the device KD trees (host threads, kdrefine.h) and uploading the
+ * scene + gathering the leaf vertices on the device.  Replaces: the "KD-tree built in %.2lfs" report of src/mesh.cpp:209. */
+int qd_scene_setup_info(const qd_scene* scene, double* kd_build_seconds, double* upload_seconds);
 
 /* Replaces: nothing in the reference (its render loop cannot fail).  Returns <0 if an asynchronous
  * launch on this scene overflowed its ray queue since the last check (synchronises the device). */

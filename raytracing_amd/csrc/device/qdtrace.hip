@@ -11,6 +11,7 @@
 #include <hipcub/hipcub.hpp>
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -1004,6 +1005,7 @@ struct qd_scene {
     bool wavefront_overflowed = false;
     int last_form = 0;                   // form of the most recent launch (the synchronous entry points retry an overflowed wavefront frame in the other)
     uint64_t kd_nodes = 0, kd_refs = 0, kd_leaves = 0, kd_max_leaf = 0;   // device tree after refinement
+    double t_kd_build = 0., t_upload = 0.;   // seconds of qd_scene_create spent building the device KD tree / uploading and gathering
 };
 
 namespace {
@@ -1342,6 +1344,13 @@ extern "C" int qd_scene_kd_info(const qd_scene* s, uint64_t* nodes, uint64_t* le
     return 0;
 }
 
+extern "C" int qd_scene_setup_info(const qd_scene* s, double* kd_build_seconds, double* upload_seconds) {
+    if (!s) return set_err("qd_scene_setup_info: null scene");
+    if (kd_build_seconds) *kd_build_seconds = s->t_kd_build;
+    if (upload_seconds) *upload_seconds = s->t_upload;
+    return 0;
+}
+
 extern "C" int qd_scene_schedule_info(const qd_scene* s, int* last_form, double* ns_per_pixel_form0, double* ns_per_pixel_form1) {
     if (!s) return set_err("qd_scene_schedule_info: null scene");
     if (last_form) *last_form = s->last_form;
@@ -1479,6 +1488,7 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
         opt.max_depth = kKdStack - 2;
         opt.rebuild = g_kd_build == 1 && g_refine_leaf > 0;
         qd_refine::Result refined;
+        const auto t_build0 = std::chrono::steady_clock::now();
         const std::string err = qd_refine::refine(desc, opt, refined);
         if (!err.empty()) { delete s; return set_err("qd_scene_create: " + err); }
         if (refined.n_refs >= (1ull << 32) || refined.n_nodes >= (1ull << 27)) { delete s; return set_err("qd_scene_create: KD tree too large for the 28-bit record index"); }
@@ -1490,7 +1500,9 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
             for (uint32_t t : T.refs) leaf_global.push_back(t + meshes_dev[mi].tri_first);
         }
         s->kd_nodes = refined.n_nodes; s->kd_refs = refined.n_refs; s->kd_leaves = refined.leaves; s->kd_max_leaf = refined.max_leaf;
+        s->t_kd_build = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build0).count();
     }
+    const auto t_upload0 = std::chrono::steady_clock::now();
     if (kd_records.size() >= (1u << 28)) { delete s; return set_err("qd_scene_create: KD tree too large for the 28-bit record index"); }
     rc |= upload(s, meshes_dev.data(), meshes_dev.size(), &d.meshes);
     rc |= upload(s, desc->hfields, desc->n_hfields, &d.hfields);
@@ -1565,6 +1577,7 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
         rc = acquire_set(s, nullptr, desc->settings.max_trace_depth, &w);
     }
     if (rc) { qd_scene_destroy(s); return -1; }
+    s->t_upload = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_upload0).count();
     *out = s;
     return 0;
 }
@@ -2045,3 +2058,4 @@ extern "C" int qd_scene_check(qd_scene* s) {
 }
 
 #include "qdcomm.h"
+#include "prep.h"

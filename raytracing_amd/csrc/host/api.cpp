@@ -27,6 +27,14 @@ extern "C" qdh_scene* qdh_load_scene(const char* path) {
     return s;
 }
 
+extern "C" void qdh_set_prep_hooks(const qdh_prep_hooks* hooks) {
+    qdh::g_prep_hooks.heightfield = hooks ? hooks->heightfield : nullptr;
+    qdh::g_prep_hooks.highmap = hooks ? hooks->highmap : nullptr;
+    qdh::g_differentiate_hook = hooks ? hooks->differentiate : nullptr;
+}
+
+extern "C" int qdh_prep_hook_calls(void) { return qdh::g_prep_hook_calls + qdh::g_differentiate_hook_calls; }
+
 extern "C" qd_scene_desc* qdh_scene_desc(qdh_scene* s) { return s ? &s->impl.desc : nullptr; }
 extern "C" void qdh_free_scene(qdh_scene* s) { delete s; }
 extern "C" void qdh_free(void* p) { free(p); }

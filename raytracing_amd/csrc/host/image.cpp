@@ -19,6 +19,9 @@
 
 namespace qdh {
 
+int (*g_differentiate_hook)(uint32_t, uint32_t, float*) = nullptr;   // qdh_set_prep_hooks
+int g_differentiate_hook_calls = 0;
+
 bool file_exists(const std::string& path_in) {
     std::string p = path_in;
     if (!p.empty() && p.back() == '/') p.pop_back();   // src/utils.cpp:37-47
@@ -443,6 +446,7 @@ bool load_image(const char* path, Image& img, std::string& err) {
 }
 
 void differentiate(Image& img) {
+    if (g_differentiate_hook && img.w && img.h && g_differentiate_hook(img.w, img.h, img.rgb.data()) == 0) { ++g_differentiate_hook_calls; return; }   // device pass; on failure the CPU code below
     // (I(x,y) - I(x+1,y), I(x,y) - I(x,y+1), 0) with wrap-around; I = plain mean (src/color.h:18)
     Image out; out.make(img.w, img.h);
     auto inten = [&](uint32_t x, uint32_t y) { float p[3]; img.get(x, y, p); return (p[0] + p[1] + p[2]) / 3; };

@@ -31,6 +31,8 @@ bool load_exr(const char* path, Image& img, std::string& err);
 bool load_image(const char* path, Image& img, std::string& err);   // by extension, like Bitmap::LoadImage
 bool save_bmp(const char* path, const float* rgb, int w, int h, size_t pitch_floats, std::string& err);
 void differentiate(Image& img);                                     // Bitmap::Differentiate
+extern int g_differentiate_hook_calls;
+extern int (*g_differentiate_hook)(uint32_t, uint32_t, float*);     // device version of it (qdh_set_prep_hooks), or null
 unsigned convert_to_8bit(double x);                                 // ConvertTo8Bit, src/utils.h:22,34
 bool file_exists(const std::string& path);
 

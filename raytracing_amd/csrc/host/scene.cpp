@@ -369,7 +369,7 @@ struct Loader {
             if (!load_image(fn.c_str(), bmp, err)) fail("line %d: %s", p->line, err.c_str());
             double blur = 0.;
             b.get_double("blur", &blur, 0, 1000);
-            h->prepare(bmp, blur);
+            { std::string perr; if (!h->prepare(bmp, blur, perr)) fail("line %d: %s", p->line, perr.c_str()); }
             b.get_bool("useOptimization", &h->use_optimization);
             g.type = QD_GEOM_HEIGHTFIELD; g.a = (int)S.hf_src.size();
             S.hf_src.push_back(std::move(h));
@@ -627,7 +627,7 @@ void SceneImpl::finalize() {
     hfields.clear(); hf_f32.clear(); hf_f64.clear();
     for (auto& hp : hf_src) {
         HeightfieldData& h = *hp;
-        if (h.use_optimization && h.highmap.empty()) h.build_highmap();
+        if (h.use_optimization && h.highmap.empty()) { std::string perr; if (!h.build_highmap(perr)) throw ParseError{perr}; }
         qd_heightfield q{};
         q.width = h.width; q.height = h.height; q.use_optimization = h.use_optimization; q.max_k = h.max_k;
         q.bbox_min[0] = h.bmin.x; q.bbox_min[1] = h.bmin.y; q.bbox_min[2] = h.bmin.z;

@@ -51,6 +51,10 @@ def lib():
         L.qd_set_pipeline.argtypes = [C.c_int]
         L.qd_set_kd_build.argtypes = [C.c_int]
         L.qd_scene_schedule_info.argtypes = [C.c_void_p, P(C.c_int), P(C.c_double), P(C.c_double)]
+        L.qd_prep_heightfield.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.qd_prep_highmap.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
+        L.qd_prep_differentiate.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+        L.qd_scene_setup_info.argtypes = [C.c_void_p, P(C.c_double), P(C.c_double)]
         L.qd_scene_kd_info.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
         L.qd_comm_unique_id.argtypes = [C.c_void_p]
         L.qd_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
@@ -255,6 +259,12 @@ class DeviceScene:
         f, a, b = C.c_int(), C.c_double(), C.c_double()
         _check(lib().qd_scene_schedule_info(self._h, C.byref(f), C.byref(a), C.byref(b)), "qd_scene_schedule_info")
         return {"form": int(f.value), "ns_per_pixel": [float(a.value), float(b.value)]}
+
+    def setup_info(self):
+        """Seconds qd_scene_create spent building the device KD trees / uploading the scene."""
+        a, b = C.c_double(), C.c_double()
+        _check(lib().qd_scene_setup_info(self._h, C.byref(a), C.byref(b)), "qd_scene_setup_info")
+        return {"kd_build_s": float(a.value), "upload_s": float(b.value)}
 
     def kd_info(self):
         v = [C.c_uint64() for _ in range(4)]

@@ -42,6 +42,25 @@ class SceneError(RuntimeError):
     pass
 
 
+class _PrepHooks(C.Structure):
+    _fields_ = [("heightfield", C.c_void_p), ("highmap", C.c_void_p), ("differentiate", C.c_void_p)]
+
+
+def prep_on_device(enable=True):
+    """Scenes loaded afterwards get their heightfield tables and differentiated bump maps from the device library's
+    kernels (qdh_set_prep_hooks with qd_prep_*; the device must be initialised) instead of the CPU code; same bits."""
+    L = lib()
+    L.qdh_set_prep_hooks.argtypes = [C.POINTER(_PrepHooks)]
+    L.qdh_set_prep_hooks.restype = None
+    if not enable:
+        L.qdh_set_prep_hooks(None)
+        return
+    from . import device
+    D = device.lib()
+    hooks = _PrepHooks(*[C.cast(getattr(D, n), C.c_void_p).value for n in ("qd_prep_heightfield", "qd_prep_highmap", "qd_prep_differentiate")])
+    L.qdh_set_prep_hooks(C.byref(hooks))
+
+
 class Scene:
     """A loaded scene: owns the flat description handed to qd_scene_create / the oracle."""
 

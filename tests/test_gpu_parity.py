@@ -14,6 +14,7 @@ from raytracing_amd import device, host, sharding
 
 pytestmark = pytest.mark.gpu
 
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
 COLOUR_TOL = 1e-4
 NEAR_TIE_BUDGET = 1e-4     # 0.01 % of pixels
 SUM_ORDER_TOL = 2e-6       # two device renders of the same pixel: float additions in a different order
@@ -321,6 +322,49 @@ def test_frame_api_errors_and_bucket_loop_cost(load_scene):
     finally:
         ds.close()
         _aa_settings(s, **old)
+
+
+def test_device_prep_tables_equal_the_host_tables(tmp_path):
+    """SURVEY 8(f).3: heightfield blur / max-heights / normals / high map and Bitmap::Differentiate as HIP kernels
+    (qd_prep_*, handed to the front end with qdh_set_prep_hooks) give the CPU code's tables bit for bit: the blurred
+    512 x 512 field of heightfield_fixed (15 x 15 gaussian), the same file without blur and without the high map, and
+    bumpmap_fixed's differentiated bump map."""
+    device.init(0)
+    plain = tmp_path / "hf_plain.qdmg"
+    src = open(os.path.join(DATA, "heightfield_fixed.qdmg")).read()
+    assert "blur 2.5" in src and "useOptimization true" in src
+    plain.write_text(src.replace("blur 2.5", "blur 0").replace("useOptimization true", "useOptimization false"))
+    for sub in ("texture", "env"):                      # file names in a scene are relative to the scene file
+        os.symlink(os.path.join(DATA, sub), tmp_path / sub)
+
+    def tables(path):
+        s = host.Scene.load(path)
+        d = s.desc
+        out = {"hf_f32": np.ctypeslib.as_array(d.hf_f32, shape=(d.n_hf_f32,)).copy() if d.n_hf_f32 else np.zeros(0, np.float32),
+               "hf_f64": np.ctypeslib.as_array(d.hf_f64, shape=(d.n_hf_f64,)).copy() if d.n_hf_f64 else np.zeros(0),
+               "texels": np.ctypeslib.as_array(d.texels, shape=(d.n_texels * 3,)).copy()}
+        if d.n_hfields:
+            h = d.hfields[0]
+            out["hf_head"] = np.array([h.width, h.height, h.use_optimization, h.max_k, *h.bbox_min, *h.bbox_max], np.float64)
+        return out
+
+    for path in (os.path.join(DATA, "heightfield_fixed.qdmg"), str(plain), os.path.join(DATA, "bumpmap_fixed.qdmg")):
+        host.prep_on_device(False)
+        cpu = tables(path)
+        host.prep_on_device(True)
+        calls = host.lib().qdh_prep_hook_calls()
+        try:
+            gpu = tables(path)
+        finally:
+            host.prep_on_device(False)
+        assert host.lib().qdh_prep_hook_calls() - calls == {"heightfield_fixed.qdmg": 2, "hf_plain.qdmg": 1, "bumpmap_fixed.qdmg": 1}[os.path.basename(path)]
+        assert cpu.keys() == gpu.keys()
+        for k in cpu:
+            assert cpu[k].shape == gpu[k].shape, (path, k)
+            assert np.array_equal(cpu[k].view(np.uint32 if cpu[k].dtype == np.float32 else np.uint64),
+                                  gpu[k].view(np.uint32 if gpu[k].dtype == np.float32 else np.uint64)), (path, k)
+    # the hooks were really used: a direct call with a bad argument fails loudly
+    assert device.lib().qd_prep_highmap(0, 0, None, 1, None) != 0
 
 
 def test_nested_layered_matches_oracle_and_too_deep_is_rejected(load_scene, tmp_path):
