@@ -112,49 +112,59 @@ public:
     void build(SubTree& out, const Box& box, const std::vector<uint32_t>& tris, int depth) {
         out.nodes.clear(); out.refs.clear();
         out.nodes.push_back(BNode{0., 0u, 0u, 3});
-        split(out, 0, box, tris, depth);
+        arena_.assign(tris.begin(), tris.end());
+        split(out, 0, box, 0, (uint32_t)tris.size(), depth);
     }
 
 private:
     const double* tv_;
     uint32_t first_;
     Options opt_;
+    // Working memory reused from node to node (a 10 M triangle mesh has 20 M nodes: an allocation or two per node was half
+    // of the build).  arena_ is a stack of triangle lists: a node's list sits at [off, off + n); its children's lists are
+    // pushed behind everything, used by the recursion and popped again.
+    std::vector<uint32_t> arena_;
+    std::vector<TriBounds> tb_;
+    std::vector<double> los_, his_, flat_, cand_;
 
-    void make_leaf(SubTree& out, size_t at, const std::vector<uint32_t>& list) {
-        out.nodes[at] = BNode{0., (uint32_t)out.refs.size(), (uint32_t)list.size(), 3};
-        out.refs.insert(out.refs.end(), list.begin(), list.end());
+    void make_leaf(SubTree& out, size_t at, size_t off, uint32_t n) {
+        out.nodes[at] = BNode{0., (uint32_t)out.refs.size(), n, 3};
+        out.refs.insert(out.refs.end(), arena_.begin() + off, arena_.begin() + off + n);
     }
 
-    void split(SubTree& out, size_t at, const Box& box, const std::vector<uint32_t>& list, int depth) {
-        const uint32_t n = (uint32_t)list.size();
+    void split(SubTree& out, size_t at, const Box& box, size_t off, uint32_t n, int depth) {
         const double area = half_area(box);
-        if (opt_.max_leaf <= 0 || (int)n <= opt_.max_leaf || depth >= opt_.max_depth || !(area > 0.)) { make_leaf(out, at, list); return; }
-        std::vector<TriBounds> tb(n);
-        for (uint32_t i = 0; i < n; ++i) tb[i] = tri_bounds(tv_, first_ + list[i], box);
+        if (opt_.max_leaf <= 0 || (int)n <= opt_.max_leaf || depth >= opt_.max_depth || !(area > 0.)) { make_leaf(out, at, off, n); return; }
+        tb_.resize(n);
+        for (uint32_t i = 0; i < n; ++i) tb_[i] = tri_bounds(tv_, first_ + arena_[off + i], box);
         double best_cost = (double)n;          // cost of staying a leaf
         int best_axis = -1;
         double best_split = 0.;
-        if (n > opt_.binned_above) binned_plane(box, tb.data(), n, 1, opt_, best_cost, best_axis, best_split);
-        std::vector<double> los(n > opt_.binned_above ? 0 : n), his(los.size()), flat, cand;
+        if (n > opt_.binned_above) binned_plane(box, tb_.data(), n, 1, opt_, best_cost, best_axis, best_split);
         for (int a = 0; a < 3 && n <= opt_.binned_above; ++a) {
             if (!(box.hi[a] > box.lo[a])) continue;
-            flat.clear(); cand.clear();
+            los_.resize(n); his_.resize(n); flat_.clear();
             for (uint32_t i = 0; i < n; ++i) {
-                los[i] = tb[i].lo[a]; his[i] = tb[i].hi[a];
-                if (los[i] == his[i]) flat.push_back(los[i]);
-                cand.push_back(los[i]); cand.push_back(his[i]);
+                los_[i] = tb_[i].lo[a]; his_[i] = tb_[i].hi[a];
+                if (los_[i] == his_[i]) flat_.push_back(los_[i]);
             }
-            std::sort(los.begin(), los.end()); std::sort(his.begin(), his.end());
-            std::sort(flat.begin(), flat.end()); std::sort(cand.begin(), cand.end());
-            cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+            std::sort(los_.begin(), los_.end()); std::sort(his_.begin(), his_.end());
+            std::sort(flat_.begin(), flat_.end());
+            cand_.resize(2 * (size_t)n);                                   // candidates = every bound, ascending, once each
+            std::merge(los_.begin(), los_.end(), his_.begin(), his_.end(), cand_.begin());
+            cand_.erase(std::unique(cand_.begin(), cand_.end()), cand_.end());
             const int u = (a + 1) % 3, v = (a + 2) % 3;
             const double du = box.hi[u] - box.lo[u], dv = box.hi[v] - box.lo[v];
-            for (double s : cand) {
+            size_t pl = 0, ph = 0, pf = 0;                                 // sweep: bounds below / at or below the candidate
+            for (double s : cand_) {
+                while (pl < n && los_[pl] < s) ++pl;                       // triangles that start before s
+                while (ph < n && his_[ph] <= s) ++ph;                      // triangles that end at or before s
+                while (pf < flat_.size() && flat_[pf] < s) ++pf;
                 if (!(s > box.lo[a] && s < box.hi[a])) continue;
-                const uint32_t below = (uint32_t)(std::lower_bound(los.begin(), los.end(), s) - los.begin());
-                const uint32_t in_plane = (uint32_t)(std::upper_bound(flat.begin(), flat.end(), s) - std::lower_bound(flat.begin(), flat.end(), s));
-                const uint32_t nl = below + in_plane;
-                const uint32_t nr = n - (uint32_t)(std::upper_bound(his.begin(), his.end(), s) - his.begin());
+                size_t pe = pf;
+                while (pe < flat_.size() && flat_[pe] == s) ++pe;          // flat triangles lying in the plane go left
+                const uint32_t nl = (uint32_t)(pl + (pe - pf));
+                const uint32_t nr = n - (uint32_t)ph;
                 const double dl = s - box.lo[a], dr = box.hi[a] - s;
                 const double al = du * dv + (du + dv) * dl, ar = du * dv + (du + dv) * dr;
                 double cost = opt_.cost_step + (al * nl + ar * nr) / area;
@@ -162,22 +172,22 @@ private:
                 if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = s; }
             }
         }
-        if (best_axis < 0) { make_leaf(out, at, list); return; }
-        std::vector<uint32_t> left, right;
-        for (uint32_t i = 0; i < n; ++i) {
-            const double lo = tb[i].lo[best_axis], hi = tb[i].hi[best_axis];
-            if (goes_left(lo, hi, best_split)) left.push_back(list[i]);
-            if (goes_right(hi, best_split)) right.push_back(list[i]);
-        }
-        if (left.size() == n && right.size() == n) { make_leaf(out, at, list); return; }
+        if (best_axis < 0) { make_leaf(out, at, off, n); return; }
+        const size_t l0 = arena_.size();
+        for (uint32_t i = 0; i < n; ++i) if (goes_left(tb_[i].lo[best_axis], tb_[i].hi[best_axis], best_split)) arena_.push_back(arena_[off + i]);
+        const size_t r0 = arena_.size();
+        for (uint32_t i = 0; i < n; ++i) if (goes_right(tb_[i].hi[best_axis], best_split)) arena_.push_back(arena_[off + i]);
+        const uint32_t nl = (uint32_t)(r0 - l0), nr = (uint32_t)(arena_.size() - r0);
+        if (nl == n && nr == n) { arena_.resize(l0); make_leaf(out, at, off, n); return; }
         const size_t c = out.nodes.size();
         out.nodes.push_back(BNode{0., 0u, 0u, 3});
         out.nodes.push_back(BNode{0., 0u, 0u, 3});
         out.nodes[at] = BNode{best_split, (uint32_t)c, 0u, (uint8_t)best_axis};
         Box bl = box, br = box;
         bl.hi[best_axis] = best_split; br.lo[best_axis] = best_split;
-        split(out, c, bl, left, depth + 1);
-        split(out, c + 1, br, right, depth + 1);
+        split(out, c, bl, l0, nl, depth + 1);
+        split(out, c + 1, br, r0, nr, depth + 1);
+        arena_.resize(l0);
     }
 };
 
@@ -192,7 +202,15 @@ struct Result {
 };
 
 // Returns an empty string, or an error message.
+#ifdef QD_REFINE_TIMING
+#define QD_REFINE_MARK(what) do { const auto now_ = std::chrono::steady_clock::now(); std::fprintf(stderr, "[kd build] %s: %.3f s\n", what, std::chrono::duration<double>(now_ - mark_).count()); mark_ = now_; } while (0)
+#else
+#define QD_REFINE_MARK(what) do {} while (0)
+#endif
 inline std::string refine(const qd_scene_desc* d, const Options& opt, Result& R) {
+#ifdef QD_REFINE_TIMING
+    auto mark_ = std::chrono::steady_clock::now();
+#endif
     R = Result();
     R.trees.resize(d->n_meshes);
     for (uint32_t mi = 0; mi < d->n_meshes; ++mi) {
@@ -212,23 +230,15 @@ inline std::string refine(const qd_scene_desc* d, const Options& opt, Result& R)
             T.nodes.push_back(BNode{0., 0u, 0u, 3});
             std::vector<uint32_t> all(m.tri_count);
             for (uint32_t i = 0; i < m.tri_count; ++i) all[i] = i;
-            std::vector<Job> todo;
-            todo.push_back(Job{0, root, std::move(all), 0});
-            std::vector<TriBounds> tb;
-            while (!todo.empty()) {
-                Job j = std::move(todo.back()); todo.pop_back();
-                const uint32_t n = (uint32_t)j.tris.size();
-                if (n <= job_tris || j.depth >= opt.max_depth - 24) { jobs.push_back(std::move(j)); continue; }
-                const uint32_t stride = std::max(1u, n / 262144u);
-                tb.resize((n + stride - 1) / stride);
-                for (uint32_t i = 0, k = 0; i < n; i += stride, ++k) tb[k] = tri_bounds(d->tri_verts, m.tri_first + j.tris[i], j.box);
-                double best_cost = (double)n; int axis = -1; double split = 0.;
-                binned_plane(j.box, tb.data(), (uint32_t)tb.size(), 1, opt, best_cost, axis, split);
-                if (axis >= 0) best_cost = 0;       // histogram counts were those of the sample: any plane found beats a leaf of this size
-                if (axis < 0) { jobs.push_back(std::move(j)); continue; }
-                std::vector<uint32_t> left, right;
-                left.reserve(n / 2 + n / 8); right.reserve(n / 2 + n / 8);
-                for (uint32_t i = 0; i < n; ++i) {
+            // Level by level, on the host cores: while a level has fewer nodes than there are threads each node's triangles are
+            // classified in parallel slices (kept in order), afterwards the nodes of a level are independent tasks.  Nodes are
+            // numbered in job order after each level, so the tree does not depend on thread timing.
+            unsigned n_thr = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+            if (m.tri_count < 200000) n_thr = 1;
+            struct Cut { int axis = -1; double split = 0.; std::vector<uint32_t> left, right; };
+            auto classify = [&](const Job& j, int axis, double split, uint32_t b, uint32_t e, std::vector<uint32_t>& left, std::vector<uint32_t>& right) {
+                left.reserve((e - b) / 2 + (e - b) / 8); right.reserve((e - b) / 2 + (e - b) / 8);
+                for (uint32_t i = b; i < e; ++i) {
                     const double* v = d->tri_verts + (size_t)(m.tri_first + j.tris[i]) * 9;
                     const double p0 = v[axis], p1 = v[axis] + v[3 + axis], p2 = v[axis] + v[6 + axis];
                     double lo = std::max(std::min(p0, std::min(p1, p2)), j.box.lo[axis]);
@@ -237,16 +247,54 @@ inline std::string refine(const qd_scene_desc* d, const Options& opt, Result& R)
                     if (goes_left(lo, hi, split)) left.push_back(j.tris[i]);
                     if (goes_right(hi, split)) right.push_back(j.tris[i]);
                 }
-                if (left.size() == n && right.size() == n) { jobs.push_back(std::move(j)); continue; }
-                const size_t c = T.nodes.size();
-                T.nodes.push_back(BNode{0., 0u, 0u, 3});
-                T.nodes.push_back(BNode{0., 0u, 0u, 3});
-                T.nodes[j.at] = BNode{split, (uint32_t)c, 0u, (uint8_t)axis};
-                Box bl = j.box, br = j.box;
-                bl.hi[axis] = split; br.lo[axis] = split;
-                std::vector<uint32_t>().swap(j.tris);
-                todo.push_back(Job{c + 1, br, std::move(right), j.depth + 1});
-                todo.push_back(Job{c, bl, std::move(left), j.depth + 1});
+            };
+            auto cut = [&](const Job& j, Cut& c, unsigned slices) {
+                const uint32_t n = (uint32_t)j.tris.size();
+                const uint32_t stride = std::max(1u, n / 262144u);
+                std::vector<TriBounds> tb((n + stride - 1) / stride);
+                for (uint32_t i = 0, k = 0; i < n; i += stride, ++k) tb[k] = tri_bounds(d->tri_verts, m.tri_first + j.tris[i], j.box);
+                double best_cost = (double)n;
+                binned_plane(j.box, tb.data(), (uint32_t)tb.size(), 1, opt, best_cost, c.axis, c.split);
+                if (c.axis < 0) return;       // (histogram counts are those of the sample: any plane found beats a leaf of this size)
+                if (slices <= 1) { classify(j, c.axis, c.split, 0, n, c.left, c.right); return; }
+                std::vector<std::vector<uint32_t>> L(slices), Rr(slices);
+                std::vector<std::thread> pool;
+                for (unsigned t = 0; t < slices; ++t)
+                    pool.emplace_back([&, t]() { classify(j, c.axis, c.split, (uint32_t)((uint64_t)n * t / slices), (uint32_t)((uint64_t)n * (t + 1) / slices), L[t], Rr[t]); });
+                for (auto& t : pool) t.join();
+                for (unsigned t = 0; t < slices; ++t) { c.left.insert(c.left.end(), L[t].begin(), L[t].end()); c.right.insert(c.right.end(), Rr[t].begin(), Rr[t].end()); }
+            };
+            std::vector<Job> level;
+            level.push_back(Job{0, root, std::move(all), 0});
+            while (!level.empty()) {
+                std::vector<Job> work;
+                for (Job& j : level) {
+                    if (j.tris.size() <= job_tris || j.depth >= opt.max_depth - 24) jobs.push_back(std::move(j));
+                    else work.push_back(std::move(j));
+                }
+                level.clear();
+                std::vector<Cut> cuts(work.size());
+                if (work.size() < n_thr) for (size_t k = 0; k < work.size(); ++k) cut(work[k], cuts[k], n_thr);
+                else {
+                    std::atomic<size_t> next_job{0};
+                    std::vector<std::thread> pool;
+                    for (unsigned t = 0; t < n_thr; ++t)
+                        pool.emplace_back([&]() { for (size_t k; (k = next_job.fetch_add(1)) < work.size();) cut(work[k], cuts[k], 1); });
+                    for (auto& t : pool) t.join();
+                }
+                for (size_t k = 0; k < work.size(); ++k) {
+                    Job& j = work[k]; Cut& c = cuts[k];
+                    const size_t n = j.tris.size();
+                    if (c.axis < 0 || (c.left.size() == n && c.right.size() == n)) { jobs.push_back(std::move(j)); continue; }
+                    const size_t ch = T.nodes.size();
+                    T.nodes.push_back(BNode{0., 0u, 0u, 3});
+                    T.nodes.push_back(BNode{0., 0u, 0u, 3});
+                    T.nodes[j.at] = BNode{c.split, (uint32_t)ch, 0u, (uint8_t)c.axis};
+                    Box bl = j.box, br = j.box;
+                    bl.hi[c.axis] = c.split; br.lo[c.axis] = c.split;
+                    level.push_back(Job{ch, bl, std::move(c.left), j.depth + 1});
+                    level.push_back(Job{ch + 1, br, std::move(c.right), j.depth + 1});
+                }
             }
         } else {
             struct Item { uint32_t src; size_t dst; Box box; int depth; };
@@ -274,6 +322,7 @@ inline std::string refine(const qd_scene_desc* d, const Options& opt, Result& R)
                 stack.push_back(Item{idx, c, bl, it.depth + 1});
             }
         }
+        QD_REFINE_MARK("top of the tree");
         // 2. one subtree per leaf, built on the host cores
         std::vector<SubTree> subs(jobs.size());
         unsigned n_thr = std::thread::hardware_concurrency();
@@ -296,23 +345,45 @@ inline std::string refine(const qd_scene_desc* d, const Options& opt, Result& R)
             for (unsigned t = 0; t < n_thr; ++t) pool.emplace_back(worker);
             for (auto& t : pool) t.join();
         }
-        // stitch: subtree node 0 lands in the slot of the leaf it replaces, the rest is appended
-        for (size_t j = 0; j < jobs.size(); ++j) {
-            const SubTree& s = subs[j];
-            const size_t node_base = T.nodes.size() - 1;      // local index i >= 1 -> node_base + i
-            const size_t ref_base = T.refs.size();
-            auto fix = [&](BNode n) {
-                if (n.axis == 3) {
-                    n.child = (uint32_t)(ref_base + n.child);
-                    R.leaves++; R.max_leaf = std::max<uint64_t>(R.max_leaf, n.count);
-                } else n.child = (uint32_t)(node_base + n.child);
-                return n;
+        QD_REFINE_MARK("subtrees");
+        // stitch: subtree node 0 lands in the slot of the leaf it replaces, the rest is appended in job order (offsets by a
+        // prefix sum, copies on the host cores)
+        {
+            std::vector<size_t> node_off(jobs.size()), ref_off(jobs.size());
+            size_t nn = T.nodes.size(), nr = T.refs.size();
+            for (size_t j = 0; j < jobs.size(); ++j) { node_off[j] = nn; nn += subs[j].nodes.size() - 1; ref_off[j] = nr; nr += subs[j].refs.size(); }
+            T.nodes.resize(nn); T.refs.resize(nr);
+            std::atomic<size_t> next_sub{0};
+            std::atomic<uint64_t> leaves{0}, max_leaf{0};
+            auto stitcher = [&]() {
+                uint64_t my_leaves = 0, my_max = 0;
+                for (size_t j; (j = next_sub.fetch_add(1)) < jobs.size();) {
+                    const SubTree& sub = subs[j];
+                    const size_t node_base = node_off[j] - 1;      // local index i >= 1 -> node_base + i
+                    const size_t ref_base = ref_off[j];
+                    auto fix = [&](BNode n) {
+                        if (n.axis == 3) { n.child = (uint32_t)(ref_base + n.child); my_leaves++; my_max = std::max<uint64_t>(my_max, n.count); }
+                        else n.child = (uint32_t)(node_base + n.child);
+                        return n;
+                    };
+                    T.nodes[jobs[j].at] = fix(sub.nodes[0]);
+                    for (size_t i = 1; i < sub.nodes.size(); ++i) T.nodes[node_base + i] = fix(sub.nodes[i]);
+                    std::copy(sub.refs.begin(), sub.refs.end(), T.refs.begin() + ref_base);
+                }
+                leaves += my_leaves;
+                uint64_t seen = max_leaf.load();
+                while (seen < my_max && !max_leaf.compare_exchange_weak(seen, my_max)) {}
             };
-            T.nodes[jobs[j].at] = fix(s.nodes[0]);
-            for (size_t i = 1; i < s.nodes.size(); ++i) T.nodes.push_back(fix(s.nodes[i]));
-            T.refs.insert(T.refs.end(), s.refs.begin(), s.refs.end());
+            if (n_thr == 1) stitcher();
+            else {
+                std::vector<std::thread> pool;
+                for (unsigned t = 0; t < n_thr; ++t) pool.emplace_back(stitcher);
+                for (auto& t : pool) t.join();
+            }
+            R.leaves += leaves.load(); R.max_leaf = std::max<uint64_t>(R.max_leaf, max_leaf.load());
         }
         R.n_nodes += T.nodes.size(); R.n_refs += T.refs.size();
+        QD_REFINE_MARK("stitch");
     }
     return std::string();
 }
