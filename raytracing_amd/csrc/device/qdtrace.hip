@@ -944,10 +944,21 @@ struct WorkSet {
     uint2* wf_deep = nullptr;
     size_t wf_cap = 0;
     uint32_t wf_gens = 0;
-    // adaptive choice of the scheduling form (qd_set_pipeline 2): events around the set's last frame
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    int timed_form = -1;                     // which form that frame ran in, -1 = nothing to read
-    uint64_t timed_slots = 0;
+    hipEvent_t blk_end[3] = {nullptr, nullptr, nullptr};   // behind this set's latest frame of block slot 0 / 1 / 2 (an event is only ever
+                                                           // recorded on this set's stream: one shared by all streams made them wait)
+};
+
+// Adaptive choice of the scheduling form (qd_set_pipeline 2): frames are grouped into blocks of kFormBlockFrames that all
+// run in one form; a block is timed from before its first frame to behind its last (events on the frames' own streams),
+// so with several frames in flight the figure is the block's THROUGHPUT, which is what the choice should maximise (the
+// latency of a lone frame ranks the forms differently: lecture7 at 4K, alone 8.3 vs 9.1 ms, two in flight 8.0 vs 7.7).
+constexpr uint32_t kFormBlockFrames = 8, kFormExploreEvery = 32;
+struct FormBlock {
+    hipEvent_t b0 = nullptr;                 // before the block's first frame, on that frame's stream
+    uint32_t used_sets = 0;                  // working sets that carried frames of the block: their blk_end[slot] events end it
+    int form = -1;                           // -1 = slot free / already read
+    uint32_t frames = 0;
+    uint64_t slots = 0;
 };
 
 // State of an AA pass between its three steps (mark / trace the taps / combine + resolve), see aa_begin.
@@ -1001,7 +1012,10 @@ struct qd_scene {
     std::vector<int> kd_node_list;       // scene nodes whose geometry is a mesh with a KD tree: one walk launch each (wavefront pipeline)
     // adaptive choice of the scheduling form: nanoseconds per pixel slot measured for each form (0 = not tried yet)
     double form_ns[2] = {0., 0.};
-    uint64_t form_frames = 0;
+    bool form_tried[2] = {false, false};
+    FormBlock blocks[3];                 // the open block and the two before it (still running / waiting to be read)
+    int cur_block = -1;
+    uint64_t n_blocks = 0;
     bool wavefront_overflowed = false;
     int last_form = 0;                   // form of the most recent launch (the synchronous entry points retry an overflowed wavefront frame in the other)
     uint64_t kd_nodes = 0, kd_refs = 0, kd_leaves = 0, kd_max_leaf = 0;   // device tree after refinement
@@ -1035,8 +1049,7 @@ void free_set(WorkSet& w) {
     for (int i = 0; i < 2; ++i) if (w.lists[i]) (void)hipFree(w.lists[i]);
     for (void* p : {(void*)w.wf_ray[0], (void*)w.wf_ray[1], (void*)w.wf_res, (void*)w.wf_ctl, (void*)w.wf_deep}) if (p) (void)hipFree(p);
     if (w.idle) (void)hipEventDestroy(w.idle);
-    if (w.t0) (void)hipEventDestroy(w.t0);
-    if (w.t1) (void)hipEventDestroy(w.t1);
+    for (hipEvent_t e : w.blk_end) if (e) (void)hipEventDestroy(e);
     w = WorkSet();
 }
 
@@ -1149,40 +1162,73 @@ int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hip
 int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hipStream_t stream);
 
 // Adaptive choice (qd_set_pipeline 2, the default): which form is faster depends on the frame -- the wavefront form wins
-// where rays have very different fates (a glass object in front of a backdrop: the reference's kdtree_test, 2x), the
-// one-kernel form where every pixel carries similar work (the 10 M triangle terrain, 1.3x).  So each form is timed on
-// real frames of the scene (HIP events around the launches of a working set, read when the set is used next) and
-// the faster one renders; every 64th frame goes to the other one, so that a change of camera or settings is noticed.
-int choose_form(qd_scene* s, WorkSet* w) {
-    if (w->timed_form >= 0 && w->t1 && hipEventQuery(w->t1) == hipSuccess) {
+// where rays have very different fates (a glass object in front of a backdrop: the reference's kdtree_test, 2x) and,
+// by a few percent, on the analytic / textured scenes; the one-kernel form where every pixel carries similar work behind
+// a deep tree (the 10 M triangle terrain, 1.3x).  So each form is timed on real frames of the scene, in blocks (see
+// FormBlock), and the faster one renders; every kFormExploreEvery-th block goes to the other one, so that a change of
+// camera or settings is noticed.
+int choose_form(qd_scene* s) {
+    const bool cur_full = s->cur_block >= 0 && s->blocks[s->cur_block].frames >= kFormBlockFrames;
+    for (int i = 0; i < 3; ++i) {                         // read the blocks that have finished
+        FormBlock& b = s->blocks[i];
+        if ((i == s->cur_block && !cur_full) || b.form < 0 || !b.frames) continue;
+        bool done = true;
+        for (int k = 0; k < kMaxWorkSets && done; ++k)
+            if ((b.used_sets >> k & 1u) && hipEventQuery(s->sets[k].blk_end[i]) != hipSuccess) done = false;
+        if (!done) continue;
         float ms = 0;
-        if (hipEventElapsedTime(&ms, w->t0, w->t1) == hipSuccess && w->timed_slots) {
-            const double ns = (double)ms * 1e6 / (double)w->timed_slots;
-            double& acc = s->form_ns[w->timed_form];
-            acc = acc == 0. ? ns : 0.75 * acc + 0.25 * ns;
+        for (int k = 0; k < kMaxWorkSets; ++k) {
+            float m = 0;
+            if ((b.used_sets >> k & 1u) && hipEventElapsedTime(&m, b.b0, s->sets[k].blk_end[i]) == hipSuccess) ms = std::max(ms, m);
         }
-        w->timed_form = -1;
+        if (ms > 0.f && b.slots) {
+            const double ns = (double)ms * 1e6 / (double)b.slots;
+            double& acc = s->form_ns[b.form];
+            acc = acc == 0. ? ns : 0.5 * acc + 0.5 * ns;
+        }
+        b.form = -1;
     }
     if (g_pipeline != 2) return g_pipeline;
     if (s->kd_node_list.size() > kWfMaxKdNodes || s->wavefront_overflowed) return 0;
-    const uint64_t k = s->form_frames++;
-    if (s->form_ns[0] == 0.) return 0;
-    if (s->form_ns[1] == 0.) return 1;
-    const int best = s->form_ns[1] < s->form_ns[0] ? 1 : 0;
-    return (k % 64 == 63) ? 1 - best : best;
+    if (s->cur_block >= 0 && !cur_full) return s->blocks[s->cur_block].form;
+    // a new block: each form once, then the faster one; every kFormExploreEvery-th block goes to the other one, so that a
+    // change of camera or settings is noticed.  While a form's first block has not been read yet the last form stays.
+    const int prev = s->last_form;
+    int form;
+    if (!s->form_tried[0]) form = 0;
+    else if (!s->form_tried[1]) form = 1;
+    else if (s->form_ns[0] == 0. || s->form_ns[1] == 0.) form = prev;
+    else {
+        const int best = s->form_ns[1] < s->form_ns[0] ? 1 : 0;
+        form = (s->n_blocks % kFormExploreEvery == kFormExploreEvery - 1) ? 1 - best : best;
+    }
+    s->form_tried[form] = true;
+    s->cur_block = (s->cur_block + 1) % 3;
+    FormBlock& nb = s->blocks[s->cur_block];              // a slot that was never read (three blocks ago) is simply reused
+    nb.form = form; nb.frames = 0; nb.slots = 0; nb.used_sets = 0;
+    ++s->n_blocks;
+    return form;
 }
 
 int launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream) {
     WorkSet* w = nullptr;
     if (acquire_set(s, stream, max_depth, &w)) return -1;
-    const int form = choose_form(s, w);
-    if (!w->t0) { HIP_TRY(hipEventCreate(&w->t0)); HIP_TRY(hipEventCreate(&w->t1)); }
-    HIP_TRY(hipEventRecord(w->t0, stream));
+    const int form = choose_form(s);
+    FormBlock* blk = (g_pipeline == 2 && s->cur_block >= 0) ? &s->blocks[s->cur_block] : nullptr;
+    if (blk) {
+        if (!blk->b0) HIP_TRY(hipEventCreate(&blk->b0));
+        if (blk->frames == 0) HIP_TRY(hipEventRecord(blk->b0, stream));
+    }
     const int rc = (form == 1 && s->kd_node_list.size() <= kWfMaxKdNodes) ? launch_wavefront(s, w, P, max_depth, stream)
                                                                            : launch_one_kernel(s, w, P, max_depth, stream);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(w->t1, stream));
-    w->timed_form = form; w->timed_slots = (uint64_t)P.n_units * kUnitPx;
+    if (blk) {
+        hipEvent_t& end = w->blk_end[s->cur_block];
+        if (!end) HIP_TRY(hipEventCreate(&end));
+        HIP_TRY(hipEventRecord(end, stream));             // behind this set's latest frame of the block
+        blk->used_sets |= 1u << (w - s->sets);
+        blk->frames++; blk->slots += (uint64_t)P.n_units * kUnitPx;
+    }
     s->last_form = form; w->last_form = form;
     return 0;
 }
@@ -1590,6 +1636,7 @@ extern "C" void qd_scene_destroy(qd_scene* s) {
     if (s->stg.host_frame) (void)hipHostFree(s->stg.host_frame);
     if (s->stg.e0) (void)hipEventDestroy(s->stg.e0);
     if (s->stg.e1) (void)hipEventDestroy(s->stg.e1);
+    for (auto& b : s->blocks) if (b.b0) (void)hipEventDestroy(b.b0);
     if (s->stats) (void)hipFree(s->stats);
     if (s->error_flag) (void)hipFree(s->error_flag);
     delete s;

@@ -131,13 +131,16 @@ class FrameRenderer:
                 self.gather(k)
         return k
 
-    def settle(self, frames=None):
+    def settle(self, blocks=2):
         """Untimed set-up: lets the library time both scheduling forms on this scene's real frames (qd_set_pipeline 2) so
-        that the frames that follow run in the faster one.  Every rank must call it (the frames are gathered)."""
-        for _ in range(frames if frames is not None else 2 * self.F + 4):
-            self.submit_frame()
-        self.wait()
-        torch.cuda.synchronize(self.dev)
+        that the frames that follow run in the faster one.  The library measures the throughput of blocks of
+        device.FORM_BLOCK_FRAMES frames, one form per block; each block is drained here so that its figure is read before
+        the next one starts.  Every rank must call it (the frames are gathered)."""
+        for _ in range(blocks):
+            for _ in range(device.FORM_BLOCK_FRAMES):
+                self.submit_frame()
+            self.wait()
+            torch.cuda.synchronize(self.dev)
 
     def wait(self, slot=None):
         """Host-wait for one slot's stream (or all of them) and return that slot's frame (rank 0) or None."""
