@@ -29,7 +29,8 @@ for fam, d in res.items():
     if fam != "trace_kernel":
         # launches per frame of this family: from the bench line (walk launches = shade launches x KD-mesh nodes)
         shade = max(cnt["wf_shade_kernel"].values()) if "wf_shade_kernel" in cnt else n_launch
-        per_frame = n_launch / (shade / (launches / (1 + max(cnt["wf_walk_kernel"].values()) / shade))) if launches else None
+        walk = max(cnt["wf_walk_kernel"].values()) if cnt.get("wf_walk_kernel") else 0      # a scene without KD meshes has no walk launches
+        per_frame = n_launch / (shade / (launches / (1 + walk / shade))) if launches else None
     frames = n_launch / per_frame if per_frame else 1
     g = {c: v / frames for c, v in d.items()}
     g["_launches_in_run"] = n_launch; g["_frames_in_run"] = frames
