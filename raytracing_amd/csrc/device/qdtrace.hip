@@ -975,11 +975,12 @@ struct AaPlan {
 // frame copies, lists and flags, the frame of qd_frame_begin): held by the scene handle, grown when a call needs more,
 // freed by qd_scene_destroy -- a loop of calls (the reference renders a frame bucket by bucket) allocates once.
 enum { kStRgb, kStHitNode, kStHitTri, kStHitDist, kStAaFrame, kStAaTaps, kStAaFirst, kStAaSlot, kStAaList, kStAaSorted, kStAaTmp,
-       kStAaA, kStAaB, kStAaAa, kStAaFlags, kStFrame, kStCount };
+       kStAaA, kStAaB, kStAaAa, kStAaFlags, kStFrame, kStFrameStats, kStCount };
 struct Staging {
     void* p[kStCount] = {};
     size_t bytes[kStCount] = {};
     hipEvent_t e0 = nullptr, e1 = nullptr;       // around the timed launches of a synchronous call
+    hipEvent_t f0 = nullptr, f1 = nullptr;       // around the launches of qd_frame_begin (a qd_render may come between begin and read)
     void* host_frame = nullptr;                  // pinned copy of the qd_frame_begin frame
     size_t host_bytes = 0;
 };
@@ -1288,25 +1289,27 @@ int stage(qd_scene* s, int which, size_t bytes, void** out) {
 // What a synchronous entry point does around its launches: counters and error flag cleared, events around the launches,
 // wait, error flag read; a wavefront frame whose queues overflowed is rendered again in the one-kernel form (whose queues
 // are bounded by construction).  `begin_only` stops after the enqueue (qd_frame_begin); finish_launch does the rest.
-int finish_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream, float* ms);
-int timed_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream, float* ms, bool begin_only = false) {
+int finish_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream, float* ms, bool frame_events);
+int timed_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream, float* ms, bool begin_only = false, bool frame_events = false) {
     Staging& g = s->stg;
-    if (!g.e0) { HIP_TRY(hipEventCreate(&g.e0)); HIP_TRY(hipEventCreate(&g.e1)); }
+    hipEvent_t& e0 = frame_events ? g.f0 : g.e0;
+    hipEvent_t& e1 = frame_events ? g.f1 : g.e1;
+    if (!e0) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); }
     WorkSet* w = nullptr;
     if (acquire_set(s, stream, max_depth, &w)) return -1;            // the set launch() is about to use: its error word
-    HIP_TRY(hipMemsetAsync(s->stats, 0, 24 * sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(s->stats + 16, 0xff, sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(s->stats + 19, 0xff, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(P.stats, 0, 24 * sizeof(unsigned long long), stream));             // the call's own counters (P.stats)
+    HIP_TRY(hipMemsetAsync(P.stats + 16, 0xff, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(P.stats + 19, 0xff, sizeof(unsigned long long), stream));
     HIP_TRY(hipMemsetAsync(s->error_flag + (w - s->sets), 0, sizeof(int), stream));
-    HIP_TRY(hipEventRecord(g.e0, stream));
+    HIP_TRY(hipEventRecord(e0, stream));
     if (launch(s, P, max_depth, stream)) return -1;
-    HIP_TRY(hipEventRecord(g.e1, stream));
-    return begin_only ? 0 : finish_launch(s, P, max_depth, stream, ms);
+    HIP_TRY(hipEventRecord(e1, stream));
+    return begin_only ? 0 : finish_launch(s, P, max_depth, stream, ms, frame_events);
 }
-int finish_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream, float* ms) {
+int finish_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream, float* ms, bool frame_events) {
     Staging& g = s->stg;
-    HIP_TRY(hipEventSynchronize(g.e1));
-    if (ms) HIP_TRY(hipEventElapsedTime(ms, g.e0, g.e1));
+    HIP_TRY(hipEventSynchronize(frame_events ? g.f1 : g.e1));
+    if (ms) HIP_TRY(hipEventElapsedTime(ms, frame_events ? g.f0 : g.e0, frame_events ? g.f1 : g.e1));
     WorkSet* w = nullptr;
     for (auto& c : s->sets) if (c.bound && c.stream == stream) { w = &c; break; }
     if (!w) return set_err("the stream's working set was taken over before the call finished (more than 8 streams on one scene)");
@@ -1317,7 +1320,7 @@ int finish_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream
         s->wavefront_overflowed = true;
         const int saved_pipeline = g_pipeline;
         g_pipeline = 0;
-        const int rc = timed_launch(s, P, max_depth, stream, ms);
+        const int rc = timed_launch(s, P, max_depth, stream, ms, false, frame_events);
         g_pipeline = saved_pipeline;
         return rc;
     }
@@ -1636,6 +1639,8 @@ extern "C" void qd_scene_destroy(qd_scene* s) {
     if (s->stg.host_frame) (void)hipHostFree(s->stg.host_frame);
     if (s->stg.e0) (void)hipEventDestroy(s->stg.e0);
     if (s->stg.e1) (void)hipEventDestroy(s->stg.e1);
+    if (s->stg.f0) (void)hipEventDestroy(s->stg.f0);
+    if (s->stg.f1) (void)hipEventDestroy(s->stg.f1);
     for (auto& b : s->blocks) if (b.b0) (void)hipEventDestroy(b.b0);
     if (s->stats) (void)hipFree(s->stats);
     if (s->error_flag) (void)hipFree(s->error_flag);
@@ -1713,7 +1718,7 @@ extern "C" int qd_frame_begin(qd_scene* s, const qd_camera* cam, const qd_settin
     const int W = st->frame_width, H = st->frame_height;
     if (W <= 0 || H <= 0) return set_err("qd_frame_begin: frame size out of range");
     FramePlan& f = s->frame;
-    if (f.launched && !f.fetched) HIP_TRY(hipEventSynchronize(s->stg.e1));      // an abandoned frame: let it drain before its buffer is reused
+    if (f.launched && !f.fetched) HIP_TRY(hipEventSynchronize(s->stg.f1));      // an abandoned frame: let it drain before its buffer is reused
     f = FramePlan();
     float* d_frame = nullptr;
     const size_t npx = (size_t)W * H;
@@ -1727,9 +1732,11 @@ extern "C" int qd_frame_begin(qd_scene* s, const qd_camera* cam, const qd_settin
     f.P.mode = 0; f.P.x0 = 0; f.P.y0 = 0; f.P.rw = W; f.P.rh = H;
     f.P.units_x = (uint32_t)(W + kUnitSide - 1) / kUnitSide;
     f.P.n_units = f.P.units_x * (uint32_t)((H + kUnitSide - 1) / kUnitSide);
-    f.P.rgb = d_frame; f.P.pitch = (size_t)W * 3; f.P.rgb_floats = npx * 3; f.P.stats = s->stats;
+    unsigned long long* d_stats = nullptr;            // counters of its own: a qd_render may come between begin and end
+    if (stage(s, kStFrameStats, (24 + 6 * 4096) * sizeof(unsigned long long), (void**)&d_stats)) return -1;
+    f.P.rgb = d_frame; f.P.pitch = (size_t)W * 3; f.P.rgb_floats = npx * 3; f.P.stats = d_stats;
     f.W = W; f.H = H; f.stream = (hipStream_t)hip_stream; f.max_depth = st->max_trace_depth;
-    if (timed_launch(s, f.P, f.max_depth, f.stream, nullptr, true)) { set_err(std::string("qd_frame_begin: ") + g_err); return -1; }
+    if (timed_launch(s, f.P, f.max_depth, f.stream, nullptr, true, true)) { set_err(std::string("qd_frame_begin: ") + g_err); return -1; }
     f.launched = true;
     return 0;
 }
@@ -1739,7 +1746,7 @@ int frame_fetch(qd_scene* s) {
     FramePlan& f = s->frame;
     if (!f.launched) return set_err("no frame in flight (qd_frame_begin first)");
     if (f.fetched) return 0;
-    if (finish_launch(s, f.P, f.max_depth, f.stream, &f.ms)) { f = FramePlan(); return -1; }
+    if (finish_launch(s, f.P, f.max_depth, f.stream, &f.ms, true)) { f = FramePlan(); return -1; }
     HIP_TRY(hipMemcpy(s->stg.host_frame, f.P.rgb, (size_t)f.W * f.H * 3 * sizeof(float), hipMemcpyDeviceToHost));
     f.fetched = true;
     return 0;
@@ -1765,7 +1772,7 @@ extern "C" int qd_frame_end(qd_scene* s, qd_stats* stats) {
     if (frame_fetch(s)) { set_err(std::string("qd_frame_end: ") + g_err); return -1; }
     if (stats) {
         unsigned long long h[8];
-        HIP_TRY(hipMemcpy(h, s->stats, sizeof h, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(h, s->frame.P.stats, sizeof h, hipMemcpyDeviceToHost));
         stats->rays = h[0]; stats->primary_rays = h[1]; stats->shadow_rays = h[2]; stats->depth_killed = h[3];
         stats->kd_nodes_visited = h[4]; stats->tris_tested = h[5]; stats->mesh_queries = h[6];
         stats->kernel_ms = s->frame.ms;

@@ -291,6 +291,10 @@ def test_frame_api_errors_and_bucket_loop_cost(load_scene):
         ds.frame_begin()
         with pytest.raises(device.DeviceError, match="bad rectangle"):
             ds.frame_read_rect(0, 0, W + 1, 8)
+        part, _, pst = ds.render(16, 16, 80, 64)                  # a rectangle call between begin and end leaves the frame alone
+        assert pst["primary_rays"] == 64 * 48
+        inside = ds.frame_read_rect(16, 16, 80, 64)
+        assert np.abs(inside - part).max() <= SUM_ORDER_TOL
         st = ds.frame_end()
         assert st["primary_rays"] == W * H
         import ctypes as C
