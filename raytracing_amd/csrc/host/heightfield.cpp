@@ -45,69 +45,67 @@ bool HeightfieldData::prepare(Image& bmp, double blur, std::string& err) {
         return true;
     }
 
-    if (blur <= 0.) {
-        for (uint32_t y = 0; y < H; ++y)
-            for (uint32_t x = 0; x < W; ++x) {
-                float p[3]; bmp.get(x, y, p);
-                const float h = (p[0] + p[1] + p[2]) / 3;
-                heights[(size_t)y * W + x] = h;
-                min_y = std::min(min_y, h); max_y = std::max(max_y, h);
-            }
-    } else {
-        for (uint32_t y = 0; y < H; ++y)
-            for (uint32_t x = 0; x < W; ++x) {
-                float p[3]; bmp.get(x, y, p);
-                const float f = (p[0] + p[1] + p[2]) / 3;
-                bmp.set(x, y, f, f, f);
-            }
-        static float gauss[128][128];
-        const int r = std::min(128, nearest_int(3 * blur));
-        for (int y = 0; y < r; ++y)
-            for (int x = 0; x < r; ++x)
-                gauss[y][x] = static_cast<float>(std::exp(-(sqr(x) + sqr(y)) / (2 * sqr(blur))) / (2 * kPi * sqr(blur)));
-        for (uint32_t y = 0; y < H; ++y)
-            for (uint32_t x = 0; x < W; ++x) {
-                float sum = 0.f;
-                for (int dy = -r + 1; dy < r; ++dy)
-                    for (int dx = -r + 1; dx < r; ++dx) {
-                        float p[3];
-                        bmp.get(x + (uint32_t)dx, y + (uint32_t)dy, p);   // unsigned wrap -> black outside
-                        sum += gauss[std::abs(dy)][std::abs(dx)] * p[0];
-                    }
-                heights[(size_t)y * W + x] = sum;
-                min_y = std::min(min_y, sum); max_y = std::max(max_y, sum);
-            }
+    // CPU version of the same per-cell passes the device kernels run (csrc/device/prep.h): a grey plane, the blurred
+    // heights, then one function of the cell index for the max-heights and one for the normals.  The order of the float
+    // additions of the blur (rows of the window top to bottom, left to right inside a row) is what fixes the bits.
+    const size_t cells = (size_t)W * H;
+    std::vector<float> grey(cells);
+    for (size_t i = 0; i < cells; ++i) {
+        const float* px = bmp.ok() ? &bmp.rgb[i * 3] : nullptr;
+        grey[i] = px ? (px[0] + px[1] + px[2]) / 3 : 0.f;
     }
+    if (blur <= 0.) heights = grey;
+    else {
+        const int r = r_dev;                                     // window half-width: weights for offsets 0 .. r-1
+        std::vector<float> weight((size_t)std::max(r, 0) * std::max(r, 0));
+        for (int j = 0; j < r; ++j)
+            for (int i = 0; i < r; ++i)
+                weight[(size_t)j * r + i] = static_cast<float>(std::exp(-(sqr(i) + sqr(j)) / (2 * sqr(blur))) / (2 * kPi * sqr(blur)));
+        auto blurred = [&](uint32_t cx, uint32_t cy) {
+            float acc = 0.f;
+            for (int oy = 1 - r; oy < r; ++oy) {
+                const uint32_t sy = cy + (uint32_t)oy;           // wraps below zero: treated as outside, which reads black
+                const float* wrow = &weight[(size_t)std::abs(oy) * r];
+                for (int ox = 1 - r; ox < r; ++ox) {
+                    const uint32_t sx = cx + (uint32_t)ox;
+                    const float sample = (sx < W && sy < H) ? grey[(size_t)sy * W + sx] : 0.f;
+                    acc += wrow[std::abs(ox)] * sample;
+                }
+            }
+            return acc;
+        };
+        for (uint32_t y = 0; y < H; ++y)
+            for (uint32_t x = 0; x < W; ++x) heights[(size_t)y * W + x] = blurred(x, y);
+    }
+    for (float h : heights) { min_y = std::min(min_y, h); max_y = std::max(max_y, h); }
     bmin = V3(0, min_y, 0);
     bmax = V3(double(W), max_y, double(H));
 
-    // max of the (up to) four corners of each cell (PopulateMaxHeights)
-    maxheights.assign((size_t)W * H, 0.f);
+    // per cell: the highest of its (up to four) corner heights, and the normal of the forward-difference plane of the
+    // nearest cell that has both forward neighbours (the last column and row repeat the one before)
+    auto corner_max = [&](uint32_t x, uint32_t y) {
+        const size_t i = (size_t)y * W + x;
+        float top = heights[i];
+        const bool right = x + 1 < W, below = y + 1 < H;
+        if (right) top = std::max(top, heights[i + 1]);
+        if (below) top = std::max(top, heights[i + W]);
+        if (right && below) top = std::max(top, heights[i + W + 1]);
+        return top;
+    };
+    auto cell_normal = [&](uint32_t x, uint32_t y) {
+        if (W < 2 || H < 2) return V3();
+        const size_t i = (size_t)std::min(y, H - 2) * W + std::min(x, W - 2);
+        const float here = heights[i];
+        const V3 along_x(1, heights[i + 1] - here, 0), along_z(0, heights[i + W] - here, 1);
+        return normalized(cross(along_z, along_x));
+    };
+    maxheights.resize(cells);
+    normals.resize(cells);
     for (uint32_t y = 0; y < H; ++y)
         for (uint32_t x = 0; x < W; ++x) {
-            float mh = heights[(size_t)y * W + x];
-            if (x < W - 1) mh = std::max(mh, heights[(size_t)y * W + x + 1]);
-            if (y < H - 1) {
-                mh = std::max(mh, heights[(size_t)(y + 1) * W + x]);
-                if (x < W - 1) mh = std::max(mh, heights[(size_t)(y + 1) * W + x + 1]);
-            }
-            maxheights[(size_t)y * W + x] = mh;
+            maxheights[(size_t)y * W + x] = corner_max(x, y);
+            normals[(size_t)y * W + x] = cell_normal(x, y);
         }
-
-    // forward-difference normals (PopulateNormals); last column / row copy their neighbour
-    normals.assign((size_t)W * H, V3());
-    for (uint32_t y = 0; y + 1 < H; ++y)
-        for (uint32_t x = 0; x + 1 < W; ++x) {
-            const float h0 = heights[(size_t)y * W + x];
-            const float hdx = heights[(size_t)y * W + x + 1];
-            const float hdy = heights[(size_t)(y + 1) * W + x];
-            const V3 vdx(1, hdx - h0, 0), vdy(0, hdy - h0, 1);
-            normals[(size_t)y * W + x] = normalized(cross(vdy, vdx));
-        }
-    if (W >= 2)
-        for (uint32_t y = 0; y < H; ++y) normals[(size_t)y * W + W - 1] = normals[(size_t)y * W + W - 2];
-    if (H >= 2)
-        for (uint32_t x = 0; x < W; ++x) normals[(size_t)(H - 1) * W + x] = normals[(size_t)(H - 2) * W + x];
     return true;
 }
 
