@@ -164,7 +164,8 @@ struct MHit { double dist, l2, l3; int tri; uint32_t n_nodes, n_tris; };
 // candidate does (x -> Sqr(x / len) is monotone), so the walk stops at the first such candidate and never looks
 // beyond the light.
 // Returns tri = -1 for a miss.  n_nodes / n_tris are filled in the counting build.
-template <bool STATS>
+// LDS_LEVELS: far-child stack levels kept in LDS (a kernel that runs fewer waves per CU affords more)
+template <bool STATS, int LDS_LEVELS = kLdsStack>
 __device__ __attribute__((noinline)) MHit mesh_query(MeshData D, int mesh_idx, DV o, DV d, bool any, double target, double rlen) {
     MHit out;
     out.dist = kInf; out.l2 = 0; out.l3 = 0; out.tri = -1; out.n_nodes = 0; out.n_tris = 0;
@@ -209,17 +210,17 @@ __device__ __attribute__((noinline)) MHit mesh_query(MeshData D, int mesh_idx, D
         // Far-child stack: the top entry in registers, the next kLdsStack entries in LDS (8 bytes each: token and the
         // interval end rounded UP to float, which only widens the interval), deeper ones in scratch.  The workgroup
         // is one wave, so the LDS block belongs to this wave alone.
-        __shared__ uint2 lds_stack[kLdsStack][64];
-        uint2 stk_deep[kKdStack - kLdsStack];
+        __shared__ uint2 lds_stack[LDS_LEVELS][64];
+        uint2 stk_deep[kKdStack - LDS_LEVELS];
         const uint32_t lane_id = threadIdx.x & 63u;
         auto stack_put = [&](int at, uint32_t tok, double t) {
             float f = (float)t;
             if ((double)f < t) f = __uint_as_float(__float_as_uint(f) + (f >= 0.f ? 1u : 0xffffffffu));   // next float up
             const uint2 e = make_uint2(tok, __float_as_uint(f));
-            if (at < kLdsStack) lds_stack[at][lane_id] = e; else stk_deep[at - kLdsStack] = e;
+            if (at < LDS_LEVELS) lds_stack[at][lane_id] = e; else stk_deep[at - LDS_LEVELS] = e;
         };
         auto stack_get = [&](int at, uint32_t& tok, double& t) {
-            const uint2 e = at < kLdsStack ? lds_stack[at][lane_id] : stk_deep[at - kLdsStack];
+            const uint2 e = at < LDS_LEVELS ? lds_stack[at][lane_id] : stk_deep[at - LDS_LEVELS];
             tok = e.x; t = (double)__uint_as_float(e.y);
         };
         int sp = 0;                                   // entries in use; entry sp-1 lives in top_*, the rest in stk_*[0 .. sp-2]

@@ -30,6 +30,7 @@ using namespace qd;
 #else
 #define QD_OUTLINE __attribute__((noinline))
 #endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -162,10 +163,9 @@ struct LaneQueue {
 // mesh query (the 10 M triangle scene, meshes + a plane: +9.5 %).
 // kGeomCsgDeep: a CSG node whose operands are not all analytic primitives (another CSG, a mesh, a heightfield): csg_generic.
 constexpr int kGeomHf = 1, kGeomCsg = 2, kGeomPrim = 4, kGeomCsgDeep = 8, kGeomAll = 15;
-template <bool STATS, int GEOM>
-__device__ QD_OUTLINE int trace_nodes(const DScene& S_, const DV& o, const DV& d, bool shadow, double target,
-                       float& transp, double& best_dw, GHit& hit, Counters& cnt) {
-    const DScene& S = uniform_const(S_);
+template <bool STATS, int GEOM, int LDS_LEVELS>
+QD_DEV int trace_nodes_body(const DScene& S, const DV& o, const DV& d, bool shadow, double target,
+                            float& transp, double& best_dw, GHit& hit, Counters& cnt) {
     int best_node = -1;
     best_dw = kInf; transp = 1.f;
     double w_dist = 0, w_l2 = 0, w_l3 = 0;
@@ -192,7 +192,7 @@ __device__ QD_OUTLINE int trace_nodes(const DScene& S_, const DV& o, const DV& d
                 hit.dist = w_dist; hit.ip = r.o + r.d * w_dist; hit.tri = w_tri; hit.mesh = g.a; hit.l2 = w_l2; hit.l3 = w_l3;
                 break;
             }
-            const MHit mh = mesh_query<STATS>(mesh_data(S), g.a, r.o, r.d, shadow, target, r.len);
+            const MHit mh = mesh_query<STATS, LDS_LEVELS>(mesh_data(S), g.a, r.o, r.d, shadow, target, r.len);
             got = mh.tri >= 0;
             if (got) { dist = mh.dist; c_tri = mh.tri; c_l2 = mh.l2; c_l3 = mh.l3; }
             if (STATS) { cnt.kd_nodes += mh.n_nodes; cnt.tris += mh.n_tris; cnt.mesh_queries += mh.n_nodes ? 1u : 0u; }
@@ -229,6 +229,13 @@ __device__ QD_OUTLINE int trace_nodes(const DScene& S_, const DV& o, const DV& d
         ++i;
     }
     return best_node;
+}
+
+// behind a real call (the kernel copies that run 4 waves per SIMD: the traversal's register allocation stays small)
+template <bool STATS, int GEOM>
+__device__ QD_OUTLINE int trace_nodes(const DScene& S_, const DV& o, const DV& d, bool shadow, double target,
+                                      float& transp, double& best_dw, GHit& hit, Counters& cnt) {
+    return trace_nodes_body<STATS, GEOM, kLdsStack>(uniform_const(S_), o, d, shadow, target, transp, best_dw, hit, cnt);
 }
 
 // World-space IntersectionInfo of the winning hit (src/geometry.cpp:331-338).
@@ -505,8 +512,15 @@ QD_DEV PixelSlot map_pixel(const Params& P, uint32_t unit, uint32_t p) {
 // Persistent lanes: a lane that finishes its pixel immediately takes the next pixel of the wave's
 // current 8x8 unit (or of a freshly fetched unit), so no lane waits for the slowest pixel of a tile.
 // RICH: bitmap / Mandelbrot / procedural textures or bump maps present (see tex_sample); GEOM: see trace_nodes.
-template <bool STATS, int GEOM, bool RICH>
-__global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene S, const Params P) {
+// FLAT: the node loop and the shaders are inlined into the kernel, which then runs 3 waves per SIMD (168 registers) with
+// 12 far-child stack levels in LDS: the hit record and the IntersectionInfo stay in registers instead of crossing two calls
+// through scratch memory.  Pays for the copy without heightfield / CSG / extra-primitive / texture code (meshes + planes:
+// +4.5 % on the 10 M triangle scene); the copies with more code in them are 20 - 50 % slower that way and keep the calls.
+// It contains no call at all -- not even the rare one for a Layered shader inside a layer, which alone costs 6 % -- so
+// launch() picks it only for scenes without such nesting.
+constexpr int kFlatWavesPerEU = 3, kFlatLdsStack = 12;
+template <bool STATS, int GEOM, bool RICH, bool FLAT = false>
+__global__ __launch_bounds__(64, FLAT ? kFlatWavesPerEU : QD_WAVES_PER_EU) void trace_kernel(const DScene S, const Params P) {
     const uint32_t lane = threadIdx.x;
     const size_t gl = (size_t)blockIdx.x * 64 + lane;
     LaneQueue q;
@@ -676,7 +690,9 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
         GHit h; double dw; float transp;
         const unsigned long long tp1 = QD_STAMP();
         t_sched += tp1 - tp0;
-        const int node = trace_nodes<STATS, GEOM>(kernarg_scene(), t.o, t.d, shadow, t.aux0, transp, dw, h, cnt);
+        int node;
+        if constexpr (FLAT) node = trace_nodes_body<STATS, GEOM, kFlatLdsStack>(S, t.o, t.d, shadow, t.aux0, transp, dw, h, cnt);
+        else node = trace_nodes<STATS, GEOM>(kernarg_scene(), t.o, t.d, shadow, t.aux0, transp, dw, h, cnt);
         const unsigned long long tp2 = QD_STAMP();
         t_trace += tp2 - tp1;
         if (shadow) {
@@ -705,11 +721,13 @@ __global__ __launch_bounds__(64, QD_WAVES_PER_EU) void trace_kernel(const DScene
                 const qd_layer l = S.layers[top.i0 + i];
                 Col blend = ldc(l.blend);
                 if (l.tex >= 0) blend = blend * tex_sample<RICH>(S, l.tex, info);
-                eval_leaf_shader<true, RICH>(kernarg_scene(), kernarg_params(), l.shader, t.w * (blend * suffix), (uint32_t)i + 1, t, depth, info, acc, q);
+                if constexpr (FLAT) eval_leaf_shader_body<false, RICH>(S, P, kernarg_scene(), kernarg_params(), l.shader, t.w * (blend * suffix), (uint32_t)i + 1, t, depth, info, acc, q);
+                else eval_leaf_shader<true, RICH>(kernarg_scene(), kernarg_params(), l.shader, t.w * (blend * suffix), (uint32_t)i + 1, t, depth, info, acc, q);
                 suffix = suffix * (mkc(1.f, 1.f, 1.f) - blend);
             }
         } else {
-            eval_leaf_shader<true, RICH>(kernarg_scene(), kernarg_params(), n.shader, t.w, 0, t, depth, info, acc, q);
+            if constexpr (FLAT) eval_leaf_shader_body<false, RICH>(S, P, kernarg_scene(), kernarg_params(), n.shader, t.w, 0, t, depth, info, acc, q);
+            else eval_leaf_shader<true, RICH>(kernarg_scene(), kernarg_params(), n.shader, t.w, 0, t, depth, info, acc, q);
         }
         t_shade += QD_STAMP() - tp2;
         } while (false);
@@ -1010,6 +1028,7 @@ struct qd_scene {
     uint32_t spawn0 = 1, spawn1 = 1;     // tasks queued per hit at depth 0 / deeper
     int geom_mask = 7;                   // kGeomHf | kGeomCsg | kGeomPrim | kGeomCsgDeep as present in the scene: selects the kernel copy
     bool rich = true;                    // bitmap / Mandelbrot / procedural textures or bump maps present
+    bool nested_layered = false;         // some Layered shader is a layer of another one (the FLAT kernel copy has no code for that)
     std::vector<int> kd_node_list;       // scene nodes whose geometry is a mesh with a KD tree: one walk launch each (wavefront pipeline)
     // adaptive choice of the scheduling form: nanoseconds per pixel slot measured for each form (0 = not tried yet)
     double form_ns[2] = {0., 0.};
@@ -1240,7 +1259,9 @@ int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hi
     P.list_cap = w->list_cap;
     HIP_TRY(hipMemsetAsync(w->queue_ctr, 0, (size_t)kPasses * kPassWords * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));       // the kernel adds colours into it
-    const uint32_t max_blocks = s->n_lanes / 64;
+    // the copy for meshes + planes without texture code runs 3 waves per SIMD (FLAT, see trace_kernel): fewer persistent waves
+    const bool flat = !g_counting && (s->geom_mask & 15) == 0 && !s->rich && !s->nested_layered;
+    const uint32_t max_blocks = flat ? s->n_lanes / 64 / (uint32_t)QD_WAVES_PER_EU * (uint32_t)kFlatWavesPerEU : s->n_lanes / 64;
     for (int pass = 0; pass < kPasses; ++pass) {
         uint32_t* ctl = w->queue_ctr + (size_t)pass * kPassWords;
         P.queue_ctr = ctl; P.out_count = ctl + 8 * kCtlStride; P.pass_done = ctl + 16 * kCtlStride;
@@ -1253,18 +1274,19 @@ int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hi
         const uint32_t grid = pass == 0 ? (P.n_units < max_blocks ? (P.n_units ? P.n_units : 1) : max_blocks) : (max_blocks + kLaterPassDiv - 1) / kLaterPassDiv;
         using Kernel = void (*)(const DScene, const Params);
 #ifdef QD_DEV_BUILD
-        static const Kernel plain[8] = {trace_kernel<false, 0, false>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>,
+        static const Kernel plain[8] = {trace_kernel<false, 0, false, true>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>,
                                         trace_kernel<false, 7, true>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>};
         static const Kernel rich[8] = {trace_kernel<false, 7, true>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>,
                                        trace_kernel<false, 7, true>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>, trace_kernel<false, 7, true>};
 #else
-        static const Kernel plain[8] = {trace_kernel<false, 0, false>, trace_kernel<false, 1, false>, trace_kernel<false, 2, false>, trace_kernel<false, 3, false>,
+        static const Kernel plain[8] = {trace_kernel<false, 0, false, true>, trace_kernel<false, 1, false>, trace_kernel<false, 2, false>, trace_kernel<false, 3, false>,
                                         trace_kernel<false, 4, false>, trace_kernel<false, 5, false>, trace_kernel<false, 6, false>, trace_kernel<false, 7, false>};
         static const Kernel rich[8] = {trace_kernel<false, 0, true>, trace_kernel<false, 1, true>, trace_kernel<false, 2, true>, trace_kernel<false, 3, true>,
                                        trace_kernel<false, 4, true>, trace_kernel<false, 5, true>, trace_kernel<false, 6, true>, trace_kernel<false, 7, true>};
 #endif
         const Kernel kernel = g_counting ? trace_kernel<true, kGeomAll, true>                       // counting: one copy, all code
                             : (s->geom_mask & kGeomCsgDeep) ? trace_kernel<false, kGeomAll, true>    // CSG over CSG / mesh / heightfield: the copy with everything
+                            : (!flat && (s->geom_mask & 7) == 0 && !s->rich) ? trace_kernel<false, 0, false>   // meshes + planes with a nested Layered
                                          : (s->rich ? rich : plain)[s->geom_mask & 7];
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, stream, s->d, P);
         HIP_TRY(hipGetLastError());
@@ -1487,9 +1509,11 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     };
     // tasks one hit can queue: the leaves of the shader tree (Layered may nest, kMaxLayerNesting levels below the top)
     std::string spawn_err;
+    bool nested_layered = false;             // a Layered shader that is a layer of another one
     std::function<bool(const qd_shader&, int, uint32_t&, uint32_t&)> tree_spawn = [&](const qd_shader& sh, int level, uint32_t& s0, uint32_t& s1) -> bool {
         if (sh.type != QD_SH_LAYERED) { s0 += leaf_spawn(sh, false); s1 += leaf_spawn(sh, true); return true; }
         if (level > kMaxLayerNesting) { spawn_err = "qd_scene_create: Layered shaders nested deeper than 4 levels"; return false; }
+        if (level >= 1) nested_layered = true;
         if (sh.i0 < 0 || sh.i1 < 0 || (uint32_t)(sh.i0 + sh.i1) > desc->n_layers) { spawn_err = "qd_scene_create: layer range out of bounds"; return false; }
         for (int l = 0; l < sh.i1; ++l) {
             const qd_layer& ly = desc->layers[sh.i0 + l];
@@ -1595,6 +1619,7 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     d.env_present = desc->env_present; d.env_bilinear = desc->env_bilinear;
     for (int f = 0; f < 6; ++f) d.env_faces[f] = desc->env_faces[f];
     s->spawn0 = spawn0; s->spawn1 = spawn1;
+    s->nested_layered = nested_layered;
     s->geom_mask = 0;
     for (uint32_t i = 0; i < desc->n_geoms; ++i) {
         const int t = desc->geoms[i].type;
