@@ -1260,7 +1260,7 @@ int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hi
     HIP_TRY(hipMemsetAsync(w->queue_ctr, 0, (size_t)kPasses * kPassWords * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));       // the kernel adds colours into it
     // the copy for meshes + planes without texture code runs 3 waves per SIMD (FLAT, see trace_kernel): fewer persistent waves
-    const bool flat = !g_counting && (s->geom_mask & 15) == 0 && !s->rich && !s->nested_layered;
+    const bool flat = !g_counting && (s->geom_mask & 15) == 0 && !s->nested_layered;
     const uint32_t max_blocks = flat ? s->n_lanes / 64 / (uint32_t)QD_WAVES_PER_EU * (uint32_t)kFlatWavesPerEU : s->n_lanes / 64;
     for (int pass = 0; pass < kPasses; ++pass) {
         uint32_t* ctl = w->queue_ctr + (size_t)pass * kPassWords;
@@ -1281,12 +1281,12 @@ int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hi
 #else
         static const Kernel plain[8] = {trace_kernel<false, 0, false, true>, trace_kernel<false, 1, false>, trace_kernel<false, 2, false>, trace_kernel<false, 3, false>,
                                         trace_kernel<false, 4, false>, trace_kernel<false, 5, false>, trace_kernel<false, 6, false>, trace_kernel<false, 7, false>};
-        static const Kernel rich[8] = {trace_kernel<false, 0, true>, trace_kernel<false, 1, true>, trace_kernel<false, 2, true>, trace_kernel<false, 3, true>,
+        static const Kernel rich[8] = {trace_kernel<false, 0, true, true>, trace_kernel<false, 1, true>, trace_kernel<false, 2, true>, trace_kernel<false, 3, true>,
                                        trace_kernel<false, 4, true>, trace_kernel<false, 5, true>, trace_kernel<false, 6, true>, trace_kernel<false, 7, true>};
 #endif
         const Kernel kernel = g_counting ? trace_kernel<true, kGeomAll, true>                       // counting: one copy, all code
                             : (s->geom_mask & kGeomCsgDeep) ? trace_kernel<false, kGeomAll, true>    // CSG over CSG / mesh / heightfield: the copy with everything
-                            : (!flat && (s->geom_mask & 7) == 0 && !s->rich) ? trace_kernel<false, 0, false>   // meshes + planes with a nested Layered
+                            : (!flat && (s->geom_mask & 7) == 0) ? (s->rich ? trace_kernel<false, 0, true> : trace_kernel<false, 0, false>)   // meshes + planes with a nested Layered
                                          : (s->rich ? rich : plain)[s->geom_mask & 7];
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, stream, s->d, P);
         HIP_TRY(hipGetLastError());
