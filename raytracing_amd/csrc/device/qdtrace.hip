@@ -1029,6 +1029,7 @@ struct qd_scene {
     int geom_mask = 7;                   // kGeomHf | kGeomCsg | kGeomPrim | kGeomCsgDeep as present in the scene: selects the kernel copy
     bool rich = true;                    // bitmap / Mandelbrot / procedural textures or bump maps present
     bool nested_layered = false;         // some Layered shader is a layer of another one (the FLAT kernel copy has no code for that)
+    bool small_mesh = false;             // some node's mesh has no KD tree (< 50 triangles): the wavefront shading kernel walks it through a call
     std::vector<int> kd_node_list;       // scene nodes whose geometry is a mesh with a KD tree: one walk launch each (wavefront pipeline)
     // adaptive choice of the scheduling form: nanoseconds per pixel slot measured for each form (0 = not tried yet)
     double form_ns[2] = {0., 0.};
@@ -1150,19 +1151,21 @@ int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hip
     HIP_TRY(hipMemsetAsync(w->wf_ctl, 0, (size_t)(max_depth + 3) * kWfGenWords * sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));
     using ShadeK = void (*)(const DScene, const Params, int);
+    // call-free copies by scene content (see wf_nodes); a scene that needs a call -- a mesh too small for a tree, a Layered
+    // shader inside a layer, CSG over CSG / mesh / heightfield -- runs the one copy that holds everything
 #ifdef QD_DEV_BUILD      // quick compile for development: mask 0 and the copy with everything only
-    static const ShadeK shade_plain[8] = {wf_shade_kernel<false, 0, false>, wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>,
-                                          wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>};
-    static const ShadeK shade_rich[8] = {wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>,
-                                         wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>, wf_shade_kernel<false, 7, true>};
+    static const ShadeK shade_plain[8] = {wf_shade_kernel<false, 0, false, false>, wf_shade_kernel<false, 7, true, false>, wf_shade_kernel<false, 7, true, false>, wf_shade_kernel<false, 7, true, false>,
+                                          wf_shade_kernel<false, 7, true, false>, wf_shade_kernel<false, 7, true, false>, wf_shade_kernel<false, 7, true, false>, wf_shade_kernel<false, 7, true, false>};
+    static const ShadeK shade_rich[8] = {wf_shade_kernel<false, 7, true, false>, wf_shade_kernel<false, 7, true, false>, wf_shade_kernel<false, 7, true, false>, wf_shade_kernel<false, 7, true, false>,
+                                         wf_shade_kernel<false, 7, true, false>, wf_shade_kernel<false, 7, true, false>, wf_shade_kernel<false, 7, true, false>, wf_shade_kernel<false, 7, true, false>};
 #else
-    static const ShadeK shade_plain[8] = {wf_shade_kernel<false, 0, false>, wf_shade_kernel<false, 1, false>, wf_shade_kernel<false, 2, false>, wf_shade_kernel<false, 3, false>,
-                                          wf_shade_kernel<false, 4, false>, wf_shade_kernel<false, 5, false>, wf_shade_kernel<false, 6, false>, wf_shade_kernel<false, 7, false>};
-    static const ShadeK shade_rich[8] = {wf_shade_kernel<false, 0, true>, wf_shade_kernel<false, 1, true>, wf_shade_kernel<false, 2, true>, wf_shade_kernel<false, 3, true>,
-                                         wf_shade_kernel<false, 4, true>, wf_shade_kernel<false, 5, true>, wf_shade_kernel<false, 6, true>, wf_shade_kernel<false, 7, true>};
+    static const ShadeK shade_plain[8] = {wf_shade_kernel<false, 0, false, false>, wf_shade_kernel<false, 1, false, false>, wf_shade_kernel<false, 2, false, false>, wf_shade_kernel<false, 3, false, false>,
+                                          wf_shade_kernel<false, 4, false, false>, wf_shade_kernel<false, 5, false, false>, wf_shade_kernel<false, 6, false, false>, wf_shade_kernel<false, 7, false, false>};
+    static const ShadeK shade_rich[8] = {wf_shade_kernel<false, 0, true, false>, wf_shade_kernel<false, 1, true, false>, wf_shade_kernel<false, 2, true, false>, wf_shade_kernel<false, 3, true, false>,
+                                         wf_shade_kernel<false, 4, true, false>, wf_shade_kernel<false, 5, true, false>, wf_shade_kernel<false, 6, true, false>, wf_shade_kernel<false, 7, true, false>};
 #endif
-    const bool deep = (s->geom_mask & kGeomCsgDeep) != 0;
-    const ShadeK sk = g_counting ? wf_shade_kernel<true, kGeomAll, true> : deep ? wf_shade_kernel<false, kGeomAll, true>
+    const bool needs_calls = (s->geom_mask & kGeomCsgDeep) != 0 || s->nested_layered || s->small_mesh;
+    const ShadeK sk = g_counting ? wf_shade_kernel<true, kGeomAll, true, true> : needs_calls ? wf_shade_kernel<false, kGeomAll, true, true>
                                  : (s->rich ? shade_rich : shade_plain)[s->geom_mask & 7];
     const uint32_t max_blocks = s->n_lanes / 64;
     const uint32_t grid0 = (uint32_t)std::min<uint64_t>(max_blocks, std::max<uint64_t>(1, (n_slots + 63) / 64));
@@ -1609,6 +1612,7 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
         for (uint32_t i = 0; i < desc->n_nodes; ++i) {
             const qd_geom& g = desc->geoms[desc->nodes[i].geom];
             if (g.type == QD_GEOM_MESH && meshes_dev[g.a].kd_root >= 0) { slot[i] = (int)s->kd_node_list.size(); s->kd_node_list.push_back((int)i); }
+            else if (g.type == QD_GEOM_MESH) s->small_mesh = true;
         }
         rc |= upload(s, slot.data(), slot.size(), &d.node_kd_slot);
     }

@@ -313,7 +313,10 @@ __global__ __launch_bounds__(64, QD_WF_WAVES) void wf_walk_kernel(const DScene S
 
 // Raytrace's node loop for one ray of the shading kernel (same rules as trace_nodes): analytic geometry, heightfields and
 // small meshes without a tree are intersected here, a KD-tree mesh is answered by the walk kernel's result record.
-template <bool STATS, int GEOM>
+// CALLS: whether the copy may contain real calls (mesh_query for a mesh too small for a tree, the nested-Layered walk,
+// csg_generic); a scene that needs none of them runs a call-free copy (a call site, however rare, costs the kernel's
+// register allocation a few percent).
+template <bool STATS, int GEOM, bool CALLS>
 QD_DEV int wf_nodes(const DScene& S, const Params& P, uint32_t ridx, const DV& o, const DV& d, bool shadow, double target,
                                    float& transp, double& best_dw, GHit& hit, Counters& cnt) {
     int best_node = -1;
@@ -346,12 +349,12 @@ QD_DEV int wf_nodes(const DScene& S, const Params& P, uint32_t ridx, const DV& o
                 dist = __longlong_as_double((long long)R[0 * cap + ridx]);
                 got = dist < kInf;
                 if (got) { c_tri = (int)(uint32_t)R[1 * cap + ridx]; c_l2 = __longlong_as_double((long long)R[2 * cap + ridx]); c_l3 = __longlong_as_double((long long)R[3 * cap + ridx]); }
-            } else {                                                     // a mesh without a tree (< 50 triangles, src/mesh.cpp:200): all its triangles
+            } else if constexpr (CALLS) {                                // a mesh without a tree (< 50 triangles, src/mesh.cpp:200): all its triangles
                 const MHit mh = mesh_query<STATS>(mesh_data(S), g.a, r.o, r.d, shadow, target, r.len);
                 got = mh.tri >= 0;
                 if (got) { dist = mh.dist; c_tri = mh.tri; c_l2 = mh.l2; c_l3 = mh.l3; }
                 if (STATS) { cnt.kd_nodes += mh.n_nodes; cnt.tris += mh.n_tris; cnt.mesh_queries += mh.n_nodes ? 1u : 0u; }
-            }
+            } else got = false;                                          // (launch() never picks this copy for such a scene)
         } else if ((GEOM & kGeomHf) && g.type == QD_GEOM_HEIGHTFIELD) {
             if (final_pass) { hf_finish(S, g.a, r.o, r.d, w_dist, hit); break; }
             got = hf_intersect<STATS>(S, g.a, r.o, r.d, dist, cnt.kd_nodes, cnt.tris);
@@ -382,7 +385,7 @@ QD_DEV int wf_nodes(const DScene& S, const Params& P, uint32_t ridx, const DV& o
 
 // The rays of generation `gen`, full width and in queue order: the node loop, then Raytrace from
 // `closestInfo.rayDir = ray.dir` on (src/main.cpp:40-55) or the shadow term (src/shadinghelper.cpp:11-18).
-template <bool STATS, int GEOM, bool RICH>
+template <bool STATS, int GEOM, bool RICH, bool CALLS>
 __global__ __launch_bounds__(64, QD_WF_SHADE_WAVES) void wf_shade_kernel(const DScene S, const Params P, const int gen) {
     const uint32_t lane = threadIdx.x;
     uint32_t* const ctl = P.wf_ctl + (size_t)gen * kWfGenWords;
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(64, QD_WF_SHADE_WAVES) void wf_shade_kernel(const D
         const uint32_t depth = t.flags_depth & kDepthMask;
         if (shadow) ++n_shadow; else ++n_rays;
         GHit h; double dw; float transp;
-        const int node = wf_nodes<STATS, GEOM>(S, P, ridx, t.o, t.d, shadow, t.aux0, transp, dw, h, cnt);
+        const int node = wf_nodes<STATS, GEOM, CALLS>(S, P, ridx, t.o, t.d, shadow, t.aux0, transp, dw, h, cnt);
         if (shadow) { add_px(P, t.pixel, t.w * (float)((double)transp * t.aux1)); continue; }
         if ((t.flags_depth & kFlagPrimary) && P.hit_node) {
             P.hit_node[t.pixel] = node;
@@ -444,11 +447,11 @@ __global__ __launch_bounds__(64, QD_WF_SHADE_WAVES) void wf_shade_kernel(const D
                 const qd_layer l = S.layers[top.i0 + i];
                 Col blend = ldc(l.blend);
                 if (l.tex >= 0) blend = blend * tex_sample<RICH>(S, l.tex, info);
-                eval_leaf_shader_body<true, RICH>(S, P, kernarg_scene(), kernarg_params(), l.shader, t.w * (blend * suffix), (uint32_t)i + 1, t, depth, info, acc, q);
+                eval_leaf_shader_body<CALLS, RICH>(S, P, kernarg_scene(), kernarg_params(), l.shader, t.w * (blend * suffix), (uint32_t)i + 1, t, depth, info, acc, q);
                 suffix = suffix * (mkc(1.f, 1.f, 1.f) - blend);
             }
         } else {
-            eval_leaf_shader_body<true, RICH>(S, P, kernarg_scene(), kernarg_params(), n.shader, t.w, 0, t, depth, info, acc, q);
+            eval_leaf_shader_body<CALLS, RICH>(S, P, kernarg_scene(), kernarg_params(), n.shader, t.w, 0, t, depth, info, acc, q);
         }
         add_px(P, t.pixel, acc);
     }
