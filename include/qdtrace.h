@@ -410,17 +410,22 @@ int qd_set_counting(int on);
 /* Replaces: nothing in the reference (its Raytrace recursion has one form).  Selects how a frame is scheduled on the GPU:
  * 0 = one persistent kernel, every lane with its own LIFO queue of ray tasks (memory bounded by queue depth x lanes);
  * 1 = wavefront pipeline: generations of rays in HBM queues, a KD walk kernel per mesh node that refills idle lanes inside
- *     its loop and a full-width shading kernel per generation (queues sized pixels x max(4, tasks per hit + 1); a
+ *     its loop and a full-width shading kernel per generation (queues sized pixels x clamp(tasks per hit + 1, 4, 8); a
  *     generation that outgrows them raises the scene's error flag: the synchronous entry points then render the call again
  *     in form 0, the asynchronous ones report it through qd_scene_check and keep the scene on form 0 afterwards);
- * 2 = (default) the faster of the two for the scene at hand: each form is timed on real frames with HIP events (read
- *     without waiting when a working set is used again), the faster one renders, every 64th frame goes to the other.
+ * 2 = (default) the faster of the two for the scene at hand: each form is timed with HIP events on frames of the scene that
+ *     ran alone on the GPU (enqueued when the scene's earlier work had finished, finished before the next launch; read
+ *     without waiting), a form's first such frame is dropped, the faster form renders, and a caller that waits for its
+ *     frames sends every 64th to the other form.  A caller that keeps several frames in flight renders a few frames one
+ *     at a time first (FrameRenderer.settle(): 6); frames that overlap are never timed, and without lone frames the
+ *     scene stays on form 0.
  *     Which one wins depends on the frame: form 1 where rays have very different fates (the reference's kdtree_test: 2x),
  *     form 0 where all pixels carry similar work (the 10 M triangle terrain: 1.3x).
  * Same arithmetic in both forms, same results up to the order of float additions.  Applies to calls made after it. */
 int qd_set_pipeline(int pipeline);
 /* What the adaptive choice has measured for a scene: the form its most recent launch ran in (0 / 1) and the device time per
- * pixel slot of each form in nanoseconds (0 = not measured yet).  Any pointer may be NULL. */
+ * pixel slot of each form in nanoseconds (0 = not measured yet); also reads the latest frame's events if that frame ran
+ * alone and has finished.  Any pointer may be NULL. */
 int qd_scene_schedule_info(const qd_scene* scene, int* last_form, double* ns_per_pixel_form0, double* ns_per_pixel_form1);
 
 /* Replaces: the leaf criterion of Mesh::BuildKD (src/mesh.cpp:218, TRIANGLES_PER_LEAF = 20 in

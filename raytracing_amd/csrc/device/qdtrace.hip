@@ -962,21 +962,22 @@ struct WorkSet {
     uint2* wf_deep = nullptr;
     size_t wf_cap = 0;
     uint32_t wf_gens = 0;
-    hipEvent_t blk_end[3] = {nullptr, nullptr, nullptr};   // behind this set's latest frame of block slot 0 / 1 / 2 (an event is only ever
-                                                           // recorded on this set's stream: one shared by all streams made them wait)
+    hipEvent_t t0 = nullptr, t1 = nullptr;   // around the set's latest frame (adaptive choice of the scheduling form; t1 also tells
+                                             // whether the set still has work in flight)
 };
 
-// Adaptive choice of the scheduling form (qd_set_pipeline 2): frames are grouped into blocks of kFormBlockFrames that all
-// run in one form; a block is timed from before its first frame to behind its last (events on the frames' own streams),
-// so with several frames in flight the figure is the block's THROUGHPUT, which is what the choice should maximise (the
-// latency of a lone frame ranks the forms differently: lecture7 at 4K, alone 8.3 vs 9.1 ms, two in flight 8.0 vs 7.7).
-constexpr uint32_t kFormBlockFrames = 8, kFormExploreEvery = 32;
-struct FormBlock {
-    hipEvent_t b0 = nullptr;                 // before the block's first frame, on that frame's stream
-    uint32_t used_sets = 0;                  // working sets that carried frames of the block: their blk_end[slot] events end it
-    int form = -1;                           // -1 = slot free / already read
-    uint32_t frames = 0;
+// Adaptive choice of the scheduling form (qd_set_pipeline 2).  The figure per form is the latency of a frame that ran ALONE
+// on the GPU: a frame that was enqueued when every working set of the scene had drained and that had finished before the
+// next one was enqueued.  Such frames are what a caller that waits for each frame produces anyway, and what
+// FrameRenderer.settle() produces on purpose before frames are put in flight; frames that overlap others are not timed
+// (their durations stretch each other, and block-wise throughput figures turned out to swing by +-30 % with the order in
+// which overlapping frames happen to finish).  Lone latency ranks the two forms like in-flight throughput on every
+// workload measured except lecture7 at 4K (alone 8.3 vs 9.1 ms, in flight 8.0 vs 7.7 ms: a 4 % loss).
+struct FormSample {
+    bool pending = false;
+    int form = 0;
     uint64_t slots = 0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;   // the working set's events (not owned)
 };
 
 // State of an AA pass between its three steps (mark / trace the taps / combine + resolve), see aa_begin.
@@ -1033,10 +1034,11 @@ struct qd_scene {
     std::vector<int> kd_node_list;       // scene nodes whose geometry is a mesh with a KD tree: one walk launch each (wavefront pipeline)
     // adaptive choice of the scheduling form: nanoseconds per pixel slot measured for each form (0 = not tried yet)
     double form_ns[2] = {0., 0.};
-    bool form_tried[2] = {false, false};
-    FormBlock blocks[3];                 // the open block and the two before it (still running / waiting to be read)
-    int cur_block = -1;
-    uint64_t n_blocks = 0;
+    uint32_t form_samples[2] = {0, 0};   // lone frames timed per form (the first is a warm-up)
+    uint32_t form_tries[2] = {0, 0};     // frames spent on a form that has no figure yet
+    FormSample sample;                   // the latest frame, if it started alone
+    bool serial_caller = false;          // the latest sample was accepted: the caller waits for its frames
+    uint64_t form_frames = 0;
     bool wavefront_overflowed = false;
     int last_form = 0;                   // form of the most recent launch (the synchronous entry points retry an overflowed wavefront frame in the other)
     uint64_t kd_nodes = 0, kd_refs = 0, kd_leaves = 0, kd_max_leaf = 0;   // device tree after refinement
@@ -1070,7 +1072,8 @@ void free_set(WorkSet& w) {
     for (int i = 0; i < 2; ++i) if (w.lists[i]) (void)hipFree(w.lists[i]);
     for (void* p : {(void*)w.wf_ray[0], (void*)w.wf_ray[1], (void*)w.wf_res, (void*)w.wf_ctl, (void*)w.wf_deep}) if (p) (void)hipFree(p);
     if (w.idle) (void)hipEventDestroy(w.idle);
-    for (hipEvent_t e : w.blk_end) if (e) (void)hipEventDestroy(e);
+    if (w.t0) (void)hipEventDestroy(w.t0);
+    if (w.t1) (void)hipEventDestroy(w.t1);
     w = WorkSet();
 }
 
@@ -1122,7 +1125,8 @@ constexpr uint32_t kGrace = QD_GRACE;
 constexpr uint32_t kWfMaxGens = 67;          // generations a frame may have: maxTraceDepth + 2
 
 // The wavefront form of a frame (wavefront.h): walk(0) shade(0) walk(1) ... walk(D + 1) shade(D + 1) on the stream.
-int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hipStream_t stream) {
+// ... its buffers first (apart from the launches, so that the adaptive choice does not time an allocation):
+int reserve_wavefront(qd_scene* s, WorkSet* w, const Params& P, uint32_t max_depth) {
     if (max_depth + 3 > kWfMaxGens) return set_err("maxTraceDepth too large for the wavefront pipeline");
     const uint64_t n_slots = (uint64_t)P.n_units * kUnitPx;
     // queue capacity: a generation holds at most (rays of the one before) x (tasks queued per hit); generation 1 is bounded
@@ -1130,7 +1134,10 @@ int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hip
     // pixels x max(4, spawn0 + 1).  An overflow raises the scene's error flag, it never writes out of bounds: the synchronous
     // entry points then render the call again in the one-kernel form (whose queues are bounded by construction), the
     // asynchronous ones report it through qd_scene_check.
-    uint64_t cap64 = n_slots * std::max<uint64_t>(4, (uint64_t)s->spawn0 + 1);
+    // ... but never more than 8 per pixel: a 25-sample glossy scene would otherwise reserve 28 entries per pixel (48 GB per
+    // working set at 4K); a scene that really fills more than that in one generation overflows once and stays on the
+    // one-kernel form.
+    uint64_t cap64 = n_slots * std::min<uint64_t>(8, std::max<uint64_t>(4, (uint64_t)s->spawn0 + 1));
     // small launches (a bucket, a rectangle that lies on glass) get up to 32 entries per pixel while that stays below 8 M entries
     cap64 = std::max<uint64_t>(cap64, std::min<uint64_t>(n_slots * 32, 8u << 20));
     cap64 = std::max<uint64_t>(cap64, 1u << 16);
@@ -1145,6 +1152,12 @@ int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hip
         HIP_TRY(hipMalloc((void**)&w->wf_res, (size_t)cap64 * kWfResWords * 8 * n_kd));
         w->wf_cap = (size_t)cap64;
     }
+    return 0;
+}
+
+int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hipStream_t stream) {
+    if (reserve_wavefront(s, w, P, max_depth)) return -1;          // (a no-op when launch() has reserved already)
+    const uint64_t n_slots = (uint64_t)P.n_units * kUnitPx;
     P.wf_ray[0] = w->wf_ray[0]; P.wf_ray[1] = w->wf_ray[1]; P.wf_res = w->wf_res; P.wf_ctl = w->wf_ctl; P.wf_deep = w->wf_deep;
     P.wf_cap = (uint32_t)w->wf_cap;
     P.error_flag = s->error_flag + (w - s->sets);
@@ -1186,72 +1199,56 @@ int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hi
 
 // Adaptive choice (qd_set_pipeline 2, the default): which form is faster depends on the frame -- the wavefront form wins
 // where rays have very different fates (a glass object in front of a backdrop: the reference's kdtree_test, 2x) and,
-// by a few percent, on the analytic / textured scenes; the one-kernel form where every pixel carries similar work behind
-// a deep tree (the 10 M triangle terrain, 1.3x).  So each form is timed on real frames of the scene, in blocks (see
-// FormBlock), and the faster one renders; every kFormExploreEvery-th block goes to the other one, so that a change of
-// camera or settings is noticed.
-int choose_form(qd_scene* s) {
-    const bool cur_full = s->cur_block >= 0 && s->blocks[s->cur_block].frames >= kFormBlockFrames;
-    for (int i = 0; i < 3; ++i) {                         // read the blocks that have finished
-        FormBlock& b = s->blocks[i];
-        if ((i == s->cur_block && !cur_full) || b.form < 0 || !b.frames) continue;
-        bool done = true;
-        for (int k = 0; k < kMaxWorkSets && done; ++k)
-            if ((b.used_sets >> k & 1u) && hipEventQuery(s->sets[k].blk_end[i]) != hipSuccess) done = false;
-        if (!done) continue;
-        float ms = 0;
-        for (int k = 0; k < kMaxWorkSets; ++k) {
-            float m = 0;
-            if ((b.used_sets >> k & 1u) && hipEventElapsedTime(&m, b.b0, s->sets[k].blk_end[i]) == hipSuccess) ms = std::max(ms, m);
-        }
-        if (ms > 0.f && b.slots) {
-            const double ns = (double)ms * 1e6 / (double)b.slots;
-            double& acc = s->form_ns[b.form];
-            acc = acc == 0. ? ns : 0.5 * acc + 0.5 * ns;
-        }
-        b.form = -1;
+// by a few percent, on the heightfield / CSG scenes; the one-kernel form where every pixel carries similar work behind
+// a deep tree (the 10 M triangle terrain, 1.5x).  So each form is timed on real frames of the scene that ran alone (see
+// FormSample) and the faster one renders; a caller that waits for its frames also sends every 64th frame to the other
+// form, so that a change of camera or settings is noticed.
+constexpr uint32_t kFormTries = 4, kFormExploreEvery = 64;
+
+// Settles the pending sample: accepted if its frame has finished by now (at_launch: before the next frame is enqueued).
+void read_sample(qd_scene* s, bool at_launch) {
+    FormSample& f = s->sample;
+    if (!f.pending) return;
+    if (hipEventQuery(f.t1) != hipSuccess) { if (at_launch) { f.pending = false; s->serial_caller = false; } return; }
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, f.t0, f.t1) == hipSuccess && ms > 0.f && f.slots) {
+        const double ns = (double)ms * 1e6 / (double)f.slots;
+        double& acc = s->form_ns[f.form];
+        if (s->form_samples[f.form]++ == 0) {}             // a form's first frame pays for loading its kernels: not a figure
+        else acc = acc == 0. ? ns : 0.5 * acc + 0.5 * ns;
+        s->serial_caller = true;
     }
+    f.pending = false;
+}
+
+int choose_form(qd_scene* s) {
     if (g_pipeline != 2) return g_pipeline;
     if (s->kd_node_list.size() > kWfMaxKdNodes || s->wavefront_overflowed) return 0;
-    if (s->cur_block >= 0 && !cur_full) return s->blocks[s->cur_block].form;
-    // a new block: each form once, then the faster one; every kFormExploreEvery-th block goes to the other one, so that a
-    // change of camera or settings is noticed.  While a form's first block has not been read yet the last form stays.
-    const int prev = s->last_form;
-    int form;
-    if (!s->form_tried[0]) form = 0;
-    else if (!s->form_tried[1]) form = 1;
-    else if (s->form_ns[0] == 0. || s->form_ns[1] == 0.) form = prev;
-    else {
-        const int best = s->form_ns[1] < s->form_ns[0] ? 1 : 0;
-        form = (s->n_blocks % kFormExploreEvery == kFormExploreEvery - 1) ? 1 - best : best;
-    }
-    s->form_tried[form] = true;
-    s->cur_block = (s->cur_block + 1) % 3;
-    FormBlock& nb = s->blocks[s->cur_block];              // a slot that was never read (three blocks ago) is simply reused
-    nb.form = form; nb.frames = 0; nb.slots = 0; nb.used_sets = 0;
-    ++s->n_blocks;
-    return form;
+    for (int f = 0; f < 2; ++f)
+        if (s->form_ns[f] == 0. && s->form_tries[f] < kFormTries) { s->form_tries[f]++; return f; }
+    if (s->form_ns[0] == 0. || s->form_ns[1] == 0.) return s->form_ns[1] != 0. ? 1 : 0;      // (callers whose frames always overlap: one-kernel form)
+    const int best = s->form_ns[1] < s->form_ns[0] ? 1 : 0;
+    if (s->serial_caller && ++s->form_frames % kFormExploreEvery == 0) return 1 - best;
+    return best;
 }
 
 int launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream) {
     WorkSet* w = nullptr;
     if (acquire_set(s, stream, max_depth, &w)) return -1;
+    read_sample(s, true);
     const int form = choose_form(s);
-    FormBlock* blk = (g_pipeline == 2 && s->cur_block >= 0) ? &s->blocks[s->cur_block] : nullptr;
-    if (blk) {
-        if (!blk->b0) HIP_TRY(hipEventCreate(&blk->b0));
-        if (blk->frames == 0) HIP_TRY(hipEventRecord(blk->b0, stream));
-    }
-    const int rc = (form == 1 && s->kd_node_list.size() <= kWfMaxKdNodes) ? launch_wavefront(s, w, P, max_depth, stream)
+    bool alone = g_pipeline == 2;                         // does this frame start on a drained GPU (as far as this scene goes)?
+    for (auto& c : s->sets) if (alone && c.t1 && hipEventQuery(c.t1) != hipSuccess) alone = false;
+    if (!w->t0) { HIP_TRY(hipEventCreate(&w->t0)); HIP_TRY(hipEventCreate(&w->t1)); }
+    const bool wavefront = form == 1 && s->kd_node_list.size() <= kWfMaxKdNodes;
+    if (wavefront && reserve_wavefront(s, w, P, max_depth)) return -1;
+    HIP_TRY(hipEventRecord(w->t0, stream));
+    const int rc = wavefront ? launch_wavefront(s, w, P, max_depth, stream)
                                                                            : launch_one_kernel(s, w, P, max_depth, stream);
     if (rc) return rc;
-    if (blk) {
-        hipEvent_t& end = w->blk_end[s->cur_block];
-        if (!end) HIP_TRY(hipEventCreate(&end));
-        HIP_TRY(hipEventRecord(end, stream));             // behind this set's latest frame of the block
-        blk->used_sets |= 1u << (w - s->sets);
-        blk->frames++; blk->slots += (uint64_t)P.n_units * kUnitPx;
-    }
+    HIP_TRY(hipEventRecord(w->t1, stream));
+    s->sample.pending = alone;
+    s->sample.form = form; s->sample.slots = (uint64_t)P.n_units * kUnitPx; s->sample.t0 = w->t0; s->sample.t1 = w->t1;
     s->last_form = form; w->last_form = form;
     return 0;
 }
@@ -1425,8 +1422,11 @@ extern "C" int qd_scene_setup_info(const qd_scene* s, double* kd_build_seconds, 
     return 0;
 }
 
-extern "C" int qd_scene_schedule_info(const qd_scene* s, int* last_form, double* ns_per_pixel_form0, double* ns_per_pixel_form1) {
-    if (!s) return set_err("qd_scene_schedule_info: null scene");
+extern "C" int qd_scene_schedule_info(const qd_scene* cs, int* last_form, double* ns_per_pixel_form0, double* ns_per_pixel_form1) {
+    if (!cs) return set_err("qd_scene_schedule_info: null scene");
+    qd_scene* s = const_cast<qd_scene*>(cs);
+    std::lock_guard<std::mutex> lock(s->mu);
+    read_sample(s, false);                   // the latest frame, if it ran alone and has finished
     if (last_form) *last_form = s->last_form;
     if (ns_per_pixel_form0) *ns_per_pixel_form0 = s->form_ns[0];
     if (ns_per_pixel_form1) *ns_per_pixel_form1 = s->form_ns[1];
@@ -1670,7 +1670,6 @@ extern "C" void qd_scene_destroy(qd_scene* s) {
     if (s->stg.e1) (void)hipEventDestroy(s->stg.e1);
     if (s->stg.f0) (void)hipEventDestroy(s->stg.f0);
     if (s->stg.f1) (void)hipEventDestroy(s->stg.f1);
-    for (auto& b : s->blocks) if (b.b0) (void)hipEventDestroy(b.b0);
     if (s->stats) (void)hipFree(s->stats);
     if (s->error_flag) (void)hipFree(s->error_flag);
     delete s;

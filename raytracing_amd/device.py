@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 _LIB_OVERRIDE = None          # development only: scripts/ A/B another build of the same kernels through use_library()
 _INIT_DEVICE = None
-FORM_BLOCK_FRAMES = 8        # kFormBlockFrames of the library: frames per block of the adaptive choice of the scheduling form
+SETTLE_FRAMES = 6            # lone frames after which the adaptive choice of the scheduling form has both figures (2 per form + 2 to average)
 
 
 class DeviceError(RuntimeError):

@@ -131,16 +131,21 @@ class FrameRenderer:
                 self.gather(k)
         return k
 
-    def settle(self, blocks=2):
+    def settle(self, frames=device.SETTLE_FRAMES):
         """Untimed set-up: lets the library time both scheduling forms on this scene's real frames (qd_set_pipeline 2) so
-        that the frames that follow run in the faster one.  The library measures the throughput of blocks of
-        device.FORM_BLOCK_FRAMES frames, one form per block; each block is drained here so that its figure is read before
-        the next one starts.  Every rank must call it (the frames are gathered)."""
-        for _ in range(blocks):
-            for _ in range(device.FORM_BLOCK_FRAMES):
-                self.submit_frame()
-            self.wait()
+        that the frames that follow run in the faster one.  The library times frames that ran alone on the GPU, so the
+        frames here are rendered one at a time (submit, wait); each form needs two of them (the first loads its kernels).
+        A frame that outgrows the wavefront queues is dropped here (the library keeps such a scene on the one-kernel
+        form).  Every rank must call it, with the same count (the frames are gathered)."""
+        for _ in range(frames):
+            k = self.submit_frame()
+            self.wait(k)
             torch.cuda.synchronize(self.dev)
+            try:
+                self.dscene.check()
+            except device.DeviceError as e:
+                if "wavefront form" not in str(e):
+                    raise
 
     def wait(self, slot=None):
         """Host-wait for one slot's stream (or all of them) and return that slot's frame (rank 0) or None."""

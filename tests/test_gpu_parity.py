@@ -515,6 +515,42 @@ def test_frame_renderer_runs_the_aa_pass_on_the_gathered_frame(load_scene):
     assert np.abs(frame - first).max() > 1e-3        # the pass changed something
 
 
+def test_adaptive_choice_times_both_forms_and_reports_setup(load_scene):
+    """qd_set_pipeline(2): after FrameRenderer.settle() both scheduling forms have a measured ns-per-pixel figure (lone
+    frames, two per form); the frames that follow -- in flight, untimed -- run in the faster one (kdtree_fixed: the forms
+    are 2x apart), and they are the lone render's whichever form traced them.  qd_scene_setup_info reports the set-up times."""
+    from raytracing_amd import renderer
+    if os.environ.get("QD_PIPELINE") not in (None, "", "2"):
+        pytest.skip("the scheduling form is pinned for this run")
+    s = load_scene("kdtree_fixed.qdmg")
+    old = _aa_settings(s, want_aa=0)
+    try:
+        fr = renderer.FrameRenderer(s, tile=32, rank=0, world=1, local_device=0, frames_in_flight=2)
+        try:
+            info = fr.dscene.setup_info()
+            assert info["kd_build_s"] >= 0. and info["upload_s"] > 0.
+            fr.settle()
+            sched = fr.dscene.schedule_info()
+            assert sched["ns_per_pixel"][0] > 0. and sched["ns_per_pixel"][1] > 0.
+            best = 0 if sched["ns_per_pixel"][0] <= sched["ns_per_pixel"][1] else 1
+            assert max(sched["ns_per_pixel"]) > 1.3 * min(sched["ns_per_pixel"])
+            for _ in range(9):                                         # frames in flight: not timed, all in the better form
+                k = fr.submit_frame()
+                assert fr.dscene.schedule_info()["form"] == best
+            frame = fr.wait(k).cpu().numpy()
+            fr.check()
+            device.set_pipeline(1 - best)
+            try:
+                ref, _, _ = fr.dscene.render()                         # the same frame, alone, in the other form
+            finally:
+                device.set_pipeline(2)
+            assert np.abs(frame - ref).max() <= SUM_ORDER_TOL
+        finally:
+            fr.dscene.close()
+    finally:
+        _aa_settings(s, **old)
+
+
 def test_frames_in_flight_give_the_single_frame(load_scene):
     """Frames on different HIP streams use separate working sets of the scene (qd_scene_bind_stream) and overlap on the
     GPU; every one of them must be the frame a lone render gives.  Ten streams on one scene also exercise the take-over
