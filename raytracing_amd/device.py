@@ -17,12 +17,26 @@ class DeviceError(RuntimeError):
     pass
 
 
+def _torch_first():
+    """A process that uses both this library and PyTorch must load PyTorch's HIP runtime first: the wheel bundles its own
+    libamdhip64 under the same soname as /opt/rocm's, the dynamic linker keeps whichever came first for both, and torch on
+    the system runtime reports "No HIP GPUs are available".  (The library itself needs no torch: a C / C++ host links
+    /opt/rocm's runtime and nothing else.)"""
+    import sys
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+
+
 def lib():
     global _LIB
     if _LIB is None:
         path = _LIB_OVERRIDE or os.path.join(_HERE, "lib", "libqdtrace.so")
         if not os.path.exists(path):
             raise DeviceError(f"{path} is missing: the HIP extension was not built (python -m raytracing_amd.build device)")
+        _torch_first()
         L = C.CDLL(path)
         P = C.POINTER
         L.qd_last_error.restype = C.c_char_p
