@@ -410,15 +410,17 @@ int qd_set_counting(int on);
 /* Replaces: nothing in the reference (its Raytrace recursion has one form).  Selects how a frame is scheduled on the GPU:
  * 0 = one persistent kernel, every lane with its own LIFO queue of ray tasks (memory bounded by queue depth x lanes);
  * 1 = wavefront pipeline: generations of rays in HBM queues, a KD walk kernel per mesh node that refills idle lanes inside
- *     its loop and a full-width shading kernel per generation (queues sized pixels x clamp(tasks per hit + 1, 4, 8); a
+ *     its loop and a full-width shading kernel per generation (queues sized pixels x (tasks per hit + 1) within 16 GB per
+ *     working set, at least 4 and, beyond the budget, at most 8 per pixel; a
  *     generation that outgrows them raises the scene's error flag: the synchronous entry points then render the call again
  *     in form 0, the asynchronous ones report it through qd_scene_check and keep the scene on form 0 afterwards);
  * 2 = (default) the faster of the two for the scene at hand: each form is timed with HIP events on frames of the scene that
  *     ran alone on the GPU (enqueued when the scene's earlier work had finished, finished before the next launch; read
  *     without waiting), a form's first such frame is dropped, the faster form renders, and a caller that waits for its
  *     frames sends every 64th to the other form.  A caller that keeps several frames in flight renders a few frames one
- *     at a time first (FrameRenderer.settle(): 6); frames that overlap are never timed, and without lone frames the
- *     scene stays on form 0.
+ *     at a time first (FrameRenderer.settle(): 6); frames that overlap are never timed.  Until there are figures the
+ *     scene renders in form 1, or in form 0 if its device tree has more than 4 M nodes or its shaders can queue more
+ *     rays per pixel than the queues of form 1 are granted.
  *     Which one wins depends on the frame: form 1 where rays have very different fates (the reference's kdtree_test: 2x),
  *     form 0 where all pixels carry similar work (the 10 M triangle terrain: 1.3x).
  * Same arithmetic in both forms, same results up to the order of float additions.  Applies to calls made after it. */

@@ -1124,6 +1124,17 @@ constexpr uint32_t kGrace = QD_GRACE;
 
 constexpr uint32_t kWfMaxGens = 67;          // generations a frame may have: maxTraceDepth + 2
 
+// Entries of a wavefront ray queue for a launch over n_slots pixel slots (see reserve_wavefront).
+uint64_t wavefront_queue_cap(const qd_scene* s, uint64_t n_slots) {
+    const size_t n_kd = std::max<size_t>(1, s->kd_node_list.size());
+    const uint64_t entry_bytes = 2ull * kEntryWords * 8 + (uint64_t)kWfResWords * 8 * n_kd;
+    const uint64_t per_px_max = std::max<uint64_t>(8, (16ull << 30) / std::max<uint64_t>(1, n_slots * entry_bytes));
+    uint64_t cap64 = n_slots * std::min<uint64_t>(per_px_max, std::max<uint64_t>(4, (uint64_t)s->spawn0 + 1));
+    // small launches (a bucket, a rectangle that lies on glass) get up to 32 entries per pixel while that stays below 8 M entries
+    cap64 = std::max<uint64_t>(cap64, std::min<uint64_t>(n_slots * 32, 8u << 20));
+    return std::max<uint64_t>(cap64, 1u << 16);
+}
+
 // The wavefront form of a frame (wavefront.h): walk(0) shade(0) walk(1) ... walk(D + 1) shade(D + 1) on the stream.
 // ... its buffers first (apart from the launches, so that the adaptive choice does not time an allocation):
 int reserve_wavefront(qd_scene* s, WorkSet* w, const Params& P, uint32_t max_depth) {
@@ -1134,15 +1145,12 @@ int reserve_wavefront(qd_scene* s, WorkSet* w, const Params& P, uint32_t max_dep
     // pixels x max(4, spawn0 + 1).  An overflow raises the scene's error flag, it never writes out of bounds: the synchronous
     // entry points then render the call again in the one-kernel form (whose queues are bounded by construction), the
     // asynchronous ones report it through qd_scene_check.
-    // ... but never more than 8 per pixel: a 25-sample glossy scene would otherwise reserve 28 entries per pixel (48 GB per
-    // working set at 4K); a scene that really fills more than that in one generation overflows once and stays on the
-    // one-kernel form.
-    uint64_t cap64 = n_slots * std::min<uint64_t>(8, std::max<uint64_t>(4, (uint64_t)s->spawn0 + 1));
-    // small launches (a bucket, a rectangle that lies on glass) get up to 32 entries per pixel while that stays below 8 M entries
-    cap64 = std::max<uint64_t>(cap64, std::min<uint64_t>(n_slots * 32, 8u << 20));
-    cap64 = std::max<uint64_t>(cap64, 1u << 16);
-    if (cap64 >= (1ull << 31)) return set_err("frame too large for the wavefront ray queues (split it into rectangles)");
+    // ... within a memory budget of 16 GB per working set, and 8 per pixel whatever they cost: a 25-sample glossy scene asks for
+    // 28 entries per pixel (12 GB at 1920x1080, where the form is up to 2x faster for such a scene; 48 GB at 4K, where it
+    // is not); a scene that really fills more than it got in one generation overflows once and stays on the one-kernel form.
     const size_t n_kd = std::max<size_t>(1, s->kd_node_list.size());
+    const uint64_t cap64 = wavefront_queue_cap(s, n_slots);
+    if (cap64 >= (1ull << 31)) return set_err("frame too large for the wavefront ray queues (split it into rectangles)");
     if (!w->wf_ctl) HIP_TRY(hipMalloc((void**)&w->wf_ctl, (size_t)(kWfMaxGens + 1) * kWfGenWords * sizeof(uint32_t)));
     if (!w->wf_deep) HIP_TRY(hipMalloc((void**)&w->wf_deep, (size_t)(kKdStack - kLdsStack) * s->n_lanes * sizeof(uint2)));
     if (cap64 > w->wf_cap) {
@@ -1221,12 +1229,25 @@ void read_sample(qd_scene* s, bool at_launch) {
     f.pending = false;
 }
 
-int choose_form(qd_scene* s) {
+// The form of a scene's first frames, before anything has been measured (a caller that renders one image never gets
+// further).  At their own sizes the wavefront form renders 14 of the 17 fixture scenes faster (1.1x .. 4.5x, kdtree_test
+// 2.6x; scripts/gpu_forms.py) and loses where a frame is launch-bound (hw9/axe_test, 0.5 against 1.0 ms) or the tree is
+// deep (the 10 M triangle terrain, 46 M records: 0.65x).  So: wavefront, unless the tree is large or the shader graph asks
+// for more queue entries per pixel than reserve_wavefront grants for the frame.
+int prior_form(const qd_scene* s, uint64_t n_slots) {
+    if (s->kd_nodes > (4u << 20)) return 0;
+    if (wavefront_queue_cap(s, n_slots) < n_slots * ((uint64_t)s->spawn0 + 1)) return 0;     // generation 1 might not fit
+    return 1;
+}
+
+int choose_form(qd_scene* s, uint64_t n_slots) {
     if (g_pipeline != 2) return g_pipeline;
     if (s->kd_node_list.size() > kWfMaxKdNodes || s->wavefront_overflowed) return 0;
-    for (int f = 0; f < 2; ++f)
+    const int first = prior_form(s, n_slots);
+    for (int f : {first, 1 - first})
         if (s->form_ns[f] == 0. && s->form_tries[f] < kFormTries) { s->form_tries[f]++; return f; }
-    if (s->form_ns[0] == 0. || s->form_ns[1] == 0.) return s->form_ns[1] != 0. ? 1 : 0;      // (callers whose frames always overlap: one-kernel form)
+    if (s->form_ns[0] == 0. && s->form_ns[1] == 0.) return first;       // (a caller whose frames always overlap and who never settles)
+    if (s->form_ns[0] == 0. || s->form_ns[1] == 0.) return s->form_ns[1] != 0. ? 1 : 0;
     const int best = s->form_ns[1] < s->form_ns[0] ? 1 : 0;
     if (s->serial_caller && ++s->form_frames % kFormExploreEvery == 0) return 1 - best;
     return best;
@@ -1236,20 +1257,24 @@ int launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream) {
     WorkSet* w = nullptr;
     if (acquire_set(s, stream, max_depth, &w)) return -1;
     read_sample(s, true);
-    const int form = choose_form(s);
+    const int form = choose_form(s, (uint64_t)P.n_units * kUnitPx);
     bool alone = g_pipeline == 2;                         // does this frame start on a drained GPU (as far as this scene goes)?
     for (auto& c : s->sets) if (alone && c.t1 && hipEventQuery(c.t1) != hipSuccess) alone = false;
     if (!w->t0) { HIP_TRY(hipEventCreate(&w->t0)); HIP_TRY(hipEventCreate(&w->t1)); }
-    const bool wavefront = form == 1 && s->kd_node_list.size() <= kWfMaxKdNodes;
-    if (wavefront && reserve_wavefront(s, w, P, max_depth)) return -1;
+    bool wavefront = form == 1 && s->kd_node_list.size() <= kWfMaxKdNodes;
+    if (wavefront && reserve_wavefront(s, w, P, max_depth)) {
+        if (g_pipeline != 2) return -1;
+        (void)hipGetLastError();                           // no room for its queues: the scene stays on the one-kernel form
+        s->wavefront_overflowed = true; wavefront = false;
+    }
     HIP_TRY(hipEventRecord(w->t0, stream));
     const int rc = wavefront ? launch_wavefront(s, w, P, max_depth, stream)
                                                                            : launch_one_kernel(s, w, P, max_depth, stream);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(w->t1, stream));
     s->sample.pending = alone;
-    s->sample.form = form; s->sample.slots = (uint64_t)P.n_units * kUnitPx; s->sample.t0 = w->t0; s->sample.t1 = w->t1;
-    s->last_form = form; w->last_form = form;
+    s->sample.form = wavefront ? 1 : 0; s->sample.slots = (uint64_t)P.n_units * kUnitPx; s->sample.t0 = w->t0; s->sample.t1 = w->t1;
+    s->last_form = w->last_form = wavefront ? 1 : 0;
     return 0;
 }
 
