@@ -9,7 +9,10 @@ if arg.endswith(".qdmg"):                      # a fixture scene instead of the 
     s.settings.want_aa = 0
 else:
     s = host.Scene.synthetic(int(arg), 42, 3840, 2160, 8, os.path.join(ROOT, "tests/golden/data/env/forest"))
+if len(sys.argv) > 3:
+    device.use_library(os.path.join(ROOT, sys.argv[3]))       # a QD_PROFILE build under build_variants/
 device.init(0)
+device.set_pipeline(0)
 ds = device.DeviceScene(s)
 rect = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 0, s.settings.frame_width, s.settings.frame_height]
 for i in range(2):
