@@ -50,6 +50,10 @@ int qdh_bucket_list(int width, int height, int32_t* rects, int cap);
 /* Bitmap::SaveBMP (src/bitmap.cpp:181-220) on a float RGB image, incl. ConvertTo8Bit quantisation. */
 int qdh_save_bmp(const char* path, const float* rgb, int width, int height, size_t row_pitch_floats);
 
+/* Bitmap::SaveEXR (src/bitmap.cpp:254-277): the float RGB image as RGBA half, alpha 1.  Written as an uncompressed
+ * scan-line OpenEXR file (the reference's Imf::RgbaOutputFile compresses with PIZ; the decoded pixels are the same). */
+int qdh_save_exr(const char* path, const float* rgb, int width, int height, size_t row_pitch_floats);
+
 /* Bitmap::LoadImage (BMP / EXR) exposed for tests: returns malloc'd float RGB (free with qdh_free). */
 float* qdh_load_image(const char* path, uint32_t* width, uint32_t* height);
 void   qdh_free(void* p);

@@ -83,6 +83,13 @@ extern "C" int qdh_save_bmp(const char* path, const float* rgb, int w, int h, si
     return 0;
 }
 
+extern "C" int qdh_save_exr(const char* path, const float* rgb, int w, int h, size_t pitch) {
+    std::string err;
+    if (!path || !rgb) { g_err = "qdh_save_exr: null argument"; return -1; }
+    if (!save_exr(path, rgb, w, h, pitch, err)) { g_err = err; return -1; }
+    return 0;
+}
+
 extern "C" float* qdh_load_image(const char* path, uint32_t* w, uint32_t* h) {
     Image img; std::string err;
     if (!load_image(path, img, err)) { g_err = err; return nullptr; }

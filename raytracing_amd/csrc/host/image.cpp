@@ -437,6 +437,76 @@ static std::string extension_upper(const char* path) {
     return e;
 }
 
+// float -> half as OpenEXR's half(float) does it: round to nearest even, overflow to infinity, small values to subnormals
+uint16_t float_to_half(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t ex = (x >> 23) & 0xffu;
+    uint32_t man = x & 0x7fffffu;
+    if (ex == 0xffu) return (uint16_t)(sign | 0x7c00u | (man ? (0x200u | (man >> 13)) : 0u));      // inf / nan
+    const int e = (int)ex - 127 + 15;
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;                      // below half of the smallest subnormal
+        man |= 0x800000u;
+        const int shift = 14 - e;                                // 14 .. 24
+        uint32_t h = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1u), half_way = 1u << (shift - 1);
+        if (rem > half_way || (rem == half_way && (h & 1u))) ++h;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((uint32_t)e << 10) | (man >> 13);
+    const uint32_t rem = man & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;      // a carry into the exponent is the right result, up to infinity
+    return (uint16_t)(sign | h);
+}
+
+// Bitmap::SaveEXR (src/bitmap.cpp:254-277): RGBA half, alpha 1.  The reference goes through Imf::RgbaOutputFile (PIZ
+// chunks); this writer emits the same image as an uncompressed scan-line file (OpenEXR file layout: magic, version 2,
+// attributes, offset table, one chunk per line with the channels A, B, G, R in that order), which any OpenEXR reader decodes
+// to the same half pixels.
+bool save_exr(const char* path, const float* rgb, int w, int h, size_t pitch, std::string& err) {
+    if (w <= 0 || h <= 0) { err = "saveEXR: empty image"; return false; }
+    FILE* fp = fopen(path, "wb");
+    if (!fp) { err = std::string("saveEXR: can't open `") + path + "'"; return false; }
+    FileCloser closer{fp};
+    std::vector<unsigned char> hd;
+    auto put = [&](const void* p, size_t n) { hd.insert(hd.end(), (const unsigned char*)p, (const unsigned char*)p + n); };
+    auto put_str = [&](const char* z) { put(z, strlen(z) + 1); };
+    auto put_i32 = [&](int32_t v) { put(&v, 4); };
+    auto put_f32 = [&](float v) { put(&v, 4); };
+    auto attr = [&](const char* name, const char* type, int32_t size) { put_str(name); put_str(type); put_i32(size); };
+    put_i32(20000630); put_i32(2);
+    attr("channels", "chlist", 4 * 18 + 1);
+    for (const char* ch : {"A", "B", "G", "R"}) { put_str(ch); put_i32(1); put_i32(0); put_i32(1); put_i32(1); }    // HALF, pLinear 0, 1x1
+    hd.push_back(0);
+    attr("compression", "compression", 1); hd.push_back(0);
+    for (const char* name : {"dataWindow", "displayWindow"}) { attr(name, "box2i", 16); put_i32(0); put_i32(0); put_i32(w - 1); put_i32(h - 1); }
+    attr("lineOrder", "lineOrder", 1); hd.push_back(0);
+    attr("pixelAspectRatio", "float", 4); put_f32(1.f);
+    attr("screenWindowCenter", "v2f", 8); put_f32(0.f); put_f32(0.f);
+    attr("screenWindowWidth", "float", 4); put_f32(1.f);
+    hd.push_back(0);
+    const uint64_t line_bytes = (uint64_t)w * 4 * 2, chunk = 8 + line_bytes;
+    const uint64_t first = hd.size() + (uint64_t)h * 8;
+    for (int y = 0; y < h; ++y) { const uint64_t off = first + (uint64_t)y * chunk; put(&off, 8); }
+    if (fwrite(hd.data(), hd.size(), 1, fp) != 1) { err = "saveEXR: write failed"; return false; }
+    std::vector<uint16_t> line((size_t)w * 4);
+    const uint16_t one = float_to_half(1.f);
+    for (int y = 0; y < h; ++y) {
+        const float* src = rgb + (size_t)y * pitch;
+        for (int x = 0; x < w; ++x) {
+            line[x] = one;
+            line[(size_t)w + x] = float_to_half(src[x * 3 + 2]);
+            line[(size_t)2 * w + x] = float_to_half(src[x * 3 + 1]);
+            line[(size_t)3 * w + x] = float_to_half(src[x * 3 + 0]);
+        }
+        const int32_t yy = y, size = (int32_t)line_bytes;
+        if (fwrite(&yy, 4, 1, fp) != 1 || fwrite(&size, 4, 1, fp) != 1 || fwrite(line.data(), (size_t)line_bytes, 1, fp) != 1) { err = "saveEXR: write failed"; return false; }
+    }
+    return true;
+}
+
 bool load_image(const char* path, Image& img, std::string& err) {
     const std::string e = extension_upper(path);
     if (e == "BMP") return load_bmp(path, img, err);

@@ -30,6 +30,8 @@ bool load_bmp(const char* path, Image& img, std::string& err);
 bool load_exr(const char* path, Image& img, std::string& err);
 bool load_image(const char* path, Image& img, std::string& err);   // by extension, like Bitmap::LoadImage
 bool save_bmp(const char* path, const float* rgb, int w, int h, size_t pitch_floats, std::string& err);
+bool save_exr(const char* path, const float* rgb, int w, int h, size_t pitch_floats, std::string& err);
+uint16_t float_to_half(float f);
 void differentiate(Image& img);                                     // Bitmap::Differentiate
 extern int g_differentiate_hook_calls;
 extern int (*g_differentiate_hook)(uint32_t, uint32_t, float*);     // device version of it (qdh_set_prep_hooks), or null

@@ -31,6 +31,8 @@ def lib():
         L.qdh_bucket_list.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int]
         L.qdh_save_bmp.restype = C.c_int
         L.qdh_save_bmp.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_size_t]
+        L.qdh_save_exr.restype = C.c_int
+        L.qdh_save_exr.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_size_t]
         L.qdh_load_image.restype = C.POINTER(C.c_float)
         L.qdh_load_image.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.qdh_free.argtypes = [C.c_void_p]
@@ -122,6 +124,14 @@ def save_bmp(path, rgb):
     rgb = np.ascontiguousarray(rgb, dtype=np.float32)
     h, w, _ = rgb.shape
     if lib().qdh_save_bmp(os.fsencode(path), rgb.ctypes.data_as(C.POINTER(C.c_float)), w, h, w * 3) != 0:
+        raise RuntimeError(lib().qdh_last_error().decode())
+
+
+def save_exr(path, rgb):
+    """Bitmap::SaveEXR (src/bitmap.cpp:254-277): RGBA half, alpha 1, uncompressed scan lines."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w, _ = rgb.shape
+    if lib().qdh_save_exr(os.fsencode(path), rgb.ctypes.data_as(C.POINTER(C.c_float)), w, h, w * 3) != 0:
         raise RuntimeError(lib().qdh_last_error().decode())
 
 

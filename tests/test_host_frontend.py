@@ -172,6 +172,38 @@ def test_exr_piz_decode_is_sane_and_bmp_roundtrip(tmp_path, data_dir):
     assert raw[:2] == b"BM" and len(raw) == 54 + 5 * 24      # rows padded to 4 bytes
 
 
+def test_exr_write_is_rgba_half_and_reads_back(tmp_path, data_dir):
+    """Bitmap::SaveEXR (src/bitmap.cpp:254-277): RGBA half, alpha 1.  The writer emits uncompressed scan lines; the pixels
+    must be the floats rounded to half the IEEE way (what OpenEXR's half(float) does; numpy's float16 is the same rule),
+    read back by this repo's reader (itself pinned on the reference's PIZ fixtures), and an HDR fixture must survive a
+    round trip exactly (its values are halves already).  Parity with OpenEXR's own reader is unpinned (no OpenEXR here)."""
+    import struct
+    rng = np.random.default_rng(7)
+    img = (rng.standard_normal((9, 13, 3)) * np.array([1e-7, 1.0, 3e4])).astype(np.float32)
+    img[0, 0] = [0.0, -0.0, 1.0]
+    img[0, 1] = [65504.0, 65519.9, 65520.0]          # largest half; rounds down to it; rounds up to infinity
+    img[0, 2] = [6.1035156e-05, 5.9604645e-08, 2.9802322e-08]   # smallest normal; smallest subnormal; half of it (ties to even: 0)
+    img[0, 3] = [2049.0, 2051.0, 1.0009765625 + 2 ** -12]       # ties to even in both directions
+    path = str(tmp_path / "t.exr")
+    host.save_exr(path, img)
+    with np.errstate(over="ignore"):
+        exp = img.astype(np.float16).astype(np.float32)
+    back = host.load_image(path)
+    assert back.shape == img.shape and np.array_equal(back.view(np.uint32), exp.view(np.uint32))
+    raw = open(path, "rb").read()
+    assert struct.unpack("<ii", raw[:8]) == (20000630, 2)
+    assert b"channels\0chlist\0" in raw and b"compression\0compression\0\x01\0\0\0\0" in raw
+    assert len(raw) == raw.index(b"screenWindowWidth") + len(b"screenWindowWidth\0float\0") + 8 + 1 + 9 * 8 + 9 * (8 + 13 * 8)
+    first_chunk = struct.unpack("<Q", raw[len(raw) - 9 * (8 + 13 * 8) - 9 * 8:][:8])[0]
+    assert struct.unpack("<ii", raw[first_chunk:first_chunk + 8]) == (0, 13 * 8)
+    assert raw[first_chunk + 8:first_chunk + 10] == struct.pack("<e", 1.0)       # the A plane comes first
+    sky = host.load_image(os.path.join(data_dir, "env", "forest", "posy.exr"))
+    host.save_exr(path, sky)
+    assert np.array_equal(host.load_image(path), sky)
+    with pytest.raises(RuntimeError):
+        host.save_exr(str(tmp_path / "no_such_dir" / "t.exr"), img)
+
+
 def test_heightfield_tables(load_scene):
     d = load_scene("heightfield_fixed.qdmg").desc
     h = d.hfields[0]
