@@ -2,7 +2,7 @@
 # per-launch kernel durations of one prof_run.py: scripts/ktrace_once.sh <lib> [mesh-n] [rect]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/ktrace_once; rm -rf "$OUT"; mkdir -p "$OUT"
-QDTRACE_LIB=$PWD/$1 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -- python3 scripts/prof_run.py ${2:-2240} ${3:-0,0,3840,2160} > "$OUT/run.log" 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -- python3 scripts/prof_run.py ${2:-2240} ${3:-0,0,3840,2160} $1 > "$OUT/run.log" 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys
 rows = [r for f in glob.glob(sys.argv[1] + "/*/*kernel_trace.csv") for r in csv.DictReader(open(f)) if "trace_kernel" in r["Kernel_Name"]]
