@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames enqueued at a time, one HIP stream each (1 = strictly one after the other; 0 = by shard size: 2 at 1 GPU, 3 at 2, 4 at 4, 6 beyond)")
+                    help="frames enqueued at a time, one HIP stream each (1 = strictly one after the other; 0 = by shard size: 4 up to 4 GPUs, 6 beyond)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", type=int, default=None, help="qd_set_pipeline: 0 = one kernel with per-lane queues, 1 = wavefront, 2 = the faster of the two, measured (library default)")
     ap.add_argument("--kd-build", type=int, default=None, help="qd_set_kd_build: 1 = device tree by SAH from the triangles, 0 = the caller's planes + refined leaves")
