@@ -550,6 +550,35 @@ def test_first_frame_runs_in_the_form_the_prior_names(load_scene):
             st.frame_width, st.frame_height, st.want_aa = old
 
 
+def test_settle_survives_a_wavefront_overflow(load_scene):
+    """A 25-sample glossy floor at 4K: the wavefront queues get 9 entries per pixel of the 27 the shader graph can fill, so
+    the frames on which settle() tries that form overflow.  settle() drops them, the library keeps the scene on the
+    one-kernel form, and the frames that follow are clean."""
+    from raytracing_amd import renderer
+    if os.environ.get("QD_PIPELINE") not in (None, "", "2"):
+        pytest.skip("the scheduling form is pinned for this run")
+    s = load_scene("hw9/dragon.qdmg")
+    st = s.settings
+    old = (st.frame_width, st.frame_height, st.want_aa)
+    st.frame_width, st.frame_height, st.want_aa = 3840, 2160, 0
+    try:
+        fr = renderer.FrameRenderer(s, tile=32, rank=0, world=1, local_device=0, frames_in_flight=2)
+        try:
+            fr.settle()
+            sched = fr.dscene.schedule_info()
+            assert sched["ns_per_pixel"][0] > 0. and sched["ns_per_pixel"][1] == 0.
+            for _ in range(3):
+                k = fr.submit_frame()
+                assert fr.dscene.schedule_info()["form"] == 0
+            frame = fr.wait(k).cpu().numpy()
+            fr.check()
+            assert np.isfinite(frame).all() and frame.max() > 0.5
+        finally:
+            fr.dscene.close()
+    finally:
+        st.frame_width, st.frame_height, st.want_aa = old
+
+
 def test_adaptive_choice_times_both_forms_and_reports_setup(load_scene):
     """qd_set_pipeline(2): after FrameRenderer.settle() both scheduling forms have a measured ns-per-pixel figure (lone
     frames, two per form); the frames that follow -- in flight, untimed -- run in the faster one (kdtree_fixed: the forms
