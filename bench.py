@@ -86,8 +86,8 @@ def cpu_baseline(scene, budget_s=12.0, gpu_frame=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="synth", help="'synth' or a scene under tests/golden/data (e.g. kdtree_fixed.qdmg)")
     ap.add_argument("--mesh-n", type=int, default=2240, help="synthetic grid size n (2*n*n triangles)")
     ap.add_argument("--width", type=int, default=None)
