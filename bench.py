@@ -203,7 +203,7 @@ def main():
     alg_bytes = per_visit * cstats["kd_nodes_visited"] + per_test * cstats["tris_tested"] + 12.0 * owned_px
 
     if rank == 0:
-        n_kd = sum(1 for i in range(scene.desc.n_nodes) if scene.desc.geoms[scene.desc.nodes[i].geom].type == 5 and scene.desc.meshes[scene.desc.geoms[scene.desc.nodes[i].geom].a].kd_root >= 0)
+        n_kd = sum(1 for i in range(scene.desc.n_nodes) if scene.desc.geoms[scene.desc.nodes[i].geom].type == 5 and (scene.desc.meshes[scene.desc.geoms[scene.desc.nodes[i].geom].a].kd_root >= 0 or scene.desc.meshes[scene.desc.geoms[scene.desc.nodes[i].geom].a].flags & 4))
         launches = 3 if form == 0 else (scene.settings.max_trace_depth + 2) * (n_kd + 1)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None

@@ -39,6 +39,16 @@ qdh_scene* qdh_synth_scene(int n, unsigned seed, int width, int height, int max_
  * override settings (frame size, AA flags, depth) before rendering. */
 qd_scene_desc* qdh_scene_desc(qdh_scene* s);
 
+/* The reference-shaped KD trees of the scene's meshes (Mesh::BuildKD, src/mesh.cpp:198-432: midpoint or "SAH" planes, 20
+ * triangles per leaf) are built ON REQUEST: libqdtrace builds the device tree from the triangles (qd_set_kd_build 1), so
+ * a load that only feeds the GPU does not pay for a tree nobody walks (2 s for 10 M triangles); such meshes carry
+ * QD_MESH_WANT_KD and kd_root -1 until then.  qdh_scene_build_kd builds them (once) and re-points the description's
+ * kd_nodes / leaf_tris / mesh statistics: what the CPU oracle walks, what qd_set_kd_build(0) refines, what the
+ * reference prints at src/mesh.cpp:211-213.  qdh_set_eager_kd(1): scenes loaded afterwards build them inside the load,
+ * as Scene::BeginRender does (src/scene.cpp:809-821). */
+int  qdh_scene_build_kd(qdh_scene* s);
+void qdh_set_eager_kd(int on);
+
 /* Recompute camera corners after changing camera parameters (Camera::BeginFrame). */
 void qdh_camera_corners(const double position[3], double yaw, double pitch, double roll,
                         double fov, double aspect, qd_camera* out);

@@ -73,7 +73,9 @@ typedef struct qd_kdnode {
     uint32_t count;
 } qd_kdnode;
 
-enum { QD_MESH_FACETED = 1, QD_MESH_BACKCULL = 2 };
+enum { QD_MESH_FACETED = 1, QD_MESH_BACKCULL = 2,
+       QD_MESH_WANT_KD = 4   /* the mesh is to be walked through a KD tree (useKDTree and >= 50 triangles, src/mesh.cpp:200) although
+                              * the description carries none (kd_root < 0): qd_scene_create builds the device tree from the triangles */ };
 
 typedef struct qd_mesh {
     uint32_t tri_first;   /* first triangle of this mesh in the global triangle arrays  */
@@ -439,19 +441,25 @@ int qd_scene_schedule_info(const qd_scene* scene, int* last_form, double* ns_per
  * triangles may resolve differently.  Applies to scenes created after the call. */
 int qd_set_kd_refine(int max_leaf_tris, double step_cost);
 
-/* Replaces: the choice of split planes in Mesh::BuildKD (src/mesh.cpp:272-372: the midpoint of the box on axis depth % 3, or
- * the 10-step "SAH" scan) for the DEVICE copy of the tree only.  mode 1 (default): the device tree is built from the
- * triangles by a surface-area heuristic over clipped triangle bounds (binned for large nodes, exact sweep below 192
- * triangles), the caller's tree is not consulted; mode 0: the caller's planes are kept and only its leaves are split
- * further (qd_set_kd_refine).  On the 10 M triangle bench mesh mode 1 visits 28 % fewer nodes and tests 39 % fewer
- * triangles per ray in a tree of 20 M instead of 46 M nodes.  The closest hit does not depend on the tree.  With
- * qd_set_kd_refine(0, .) the caller's tree is used as it is, whatever the mode.  Applies to scenes created after the call. */
+/* Replaces: Mesh::BuildKD (src/mesh.cpp:198-432: planes at the midpoint of the box on axis depth % 3, or by the 10-step
+ * "SAH" scan; 20 triangles per leaf) for the DEVICE copy of the tree only.
+ *   mode 1 (default): the device tree is built ON THE DEVICE from the triangles (HIP kernels, csrc/device/kdbuild.h: a
+ *           level of the tree per round; 0.2 s for 10 M triangles) by a surface-area heuristic over clipped triangle
+ *           bounds (64 bins per axis for nodes above 192 triangles, exact sweep below), triangles classified against a
+ *           plane as PartitionTriangle does (src/mesh.cpp:412-432); the caller's tree is not consulted and need not
+ *           exist (a mesh with QD_MESH_WANT_KD and kd_root -1 gets its tree here);
+ *   mode 2: the same tree (the same planes, node for node, below 524 288 triangles) built by host threads (kdrefine.h:
+ *           1.2 s for 10 M triangles on 16 cores) -- kept as the check of mode 1;
+ *   mode 0: the caller's planes are kept and only its leaves are split further (qd_set_kd_refine); needs the caller's tree.
+ * On the 10 M triangle bench mesh modes 1 / 2 visit 28 % fewer nodes and test 39 % fewer triangles per ray than mode 0, in a
+ * tree of 20 M instead of 46 M nodes.  The closest hit does not depend on the tree.  With qd_set_kd_refine(0, .) the
+ * caller's tree is used as it is, whatever the mode.  Applies to scenes created after the call. */
 int qd_set_kd_build(int mode);
 
 /* Size of the device tree of a scene (after refinement): nodes, leaf references, leaves, largest leaf.
  * Any pointer may be NULL.  The reference prints the same figures for its own tree at src/mesh.cpp:211-213. */
 int qd_scene_kd_info(const qd_scene* scene, uint64_t* nodes, uint64_t* leaf_refs, uint64_t* leaves, uint64_t* max_leaf);
-/* Where qd_scene_create spent its time (seconds): building the device KD trees (host threads, kdrefine.h) and uploading the
+/* Where qd_scene_create spent its time (seconds): building the device KD trees (kdbuild.h on the device, or kdrefine.h on host threads) and uploading the
  * scene + gathering the leaf vertices on the device.  Replaces: the "KD-tree built in %.2lfs" report of src/mesh.cpp:209. */
 int qd_scene_setup_info(const qd_scene* scene, double* kd_build_seconds, double* upload_seconds);
 

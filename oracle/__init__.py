@@ -65,6 +65,7 @@ REF_RECORD = np.dtype([("node", "<i4"), ("pad", "<i4"), ("dist", "<f8"), ("ip", 
 
 def trace_rays(scene, rays):
     """Raytrace's node loop + bump + Shade for explicit rays (n x 6 f64): records in oracle/ref_driver.cpp's layout."""
+    scene.ensure_kd()          # the reference-shaped trees: Mesh::Intersect's recursive walk (src/mesh.cpp:58-92) needs them
     rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 6)
     out = np.zeros(len(rays), REF_RECORD)
     if lib().orc_trace_rays(scene.desc_ptr, len(rays), rays.ctypes.data, out.ctypes.data) != 0:
@@ -74,6 +75,7 @@ def trace_rays(scene, rays):
 
 def render_rect(scene, x0, y0, x1, y1, camera=None, settings=None, hits=False, rng_mode=1, threads=None):
     """Trace the pixel rectangle; returns (rgb[h,w,3] f32, hits or None, stats dict)."""
+    scene.ensure_kd()          # the reference-shaped trees: Mesh::Intersect's recursive walk (src/mesh.cpp:58-92) needs them
     threads = threads or min(8, os.cpu_count() or 1)
     w, h = x1 - x0, y1 - y0
     rgb = np.zeros((h, w, 3), np.float32)
@@ -91,6 +93,7 @@ def render_rect(scene, x0, y0, x1, y1, camera=None, settings=None, hits=False, r
 
 
 def render_pixels(scene, xy, camera=None, settings=None, hits=False, rng_mode=1, threads=None):
+    scene.ensure_kd()          # the reference-shaped trees: Mesh::Intersect's recursive walk (src/mesh.cpp:58-92) needs them
     threads = threads or min(8, os.cpu_count() or 1)
     xy = np.ascontiguousarray(xy, np.int32).reshape(-1, 2)
     n = xy.shape[0]
@@ -110,6 +113,7 @@ def render_pixels(scene, xy, camera=None, settings=None, hits=False, rng_mode=1,
 
 def render_frame(scene, rng_mode=0):
     """The reference's Render(): simple pass + AA pass, bucket order, single thread."""
+    scene.ensure_kd()          # the reference-shaped trees: Mesh::Intersect's recursive walk (src/mesh.cpp:58-92) needs them
     s = scene.settings
     rgb = np.zeros((s.frame_height, s.frame_width, 3), np.float32)
     st = OrcStats()

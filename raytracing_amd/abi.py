@@ -103,4 +103,5 @@ QDTRACE_SYMBOLS = ["qd_init", "qd_set_counting", "qd_scene_check", "qd_scene_set
                    "qd_comm_unique_id", "qd_comm_create", "qd_comm_destroy", "qd_comm_gather_async", "qd_comm_broadcast_async", "qd_gather_frame_async",
                    "qd_prep_heightfield", "qd_prep_highmap", "qd_prep_differentiate"]
 QDHOST_SYMBOLS = ["qdh_load_scene", "qdh_synth_scene", "qdh_scene_desc", "qdh_camera_corners", "qdh_bucket_list",
-                  "qdh_save_bmp", "qdh_save_exr", "qdh_load_image", "qdh_free", "qdh_free_scene", "qdh_last_error", "qdh_math_probe", "qdh_set_prep_hooks", "qdh_prep_hook_calls"]
+                  "qdh_save_bmp", "qdh_save_exr", "qdh_load_image", "qdh_free", "qdh_free_scene", "qdh_last_error", "qdh_math_probe", "qdh_set_prep_hooks", "qdh_prep_hook_calls",
+                  "qdh_scene_build_kd", "qdh_set_eager_kd"]

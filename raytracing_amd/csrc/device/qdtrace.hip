@@ -22,6 +22,7 @@
 #include "dshade.h"
 #include "qdtrace.h"
 #include "kdrefine.h"
+#include "kdbuild.h"
 
 using namespace qd;
 
@@ -931,7 +932,7 @@ bool g_counting = false;
 int g_pipeline = 2;           // qd_set_pipeline: 0 = one persistent kernel with per-lane LIFO queues, 1 = wavefront pipeline (wavefront.h), 2 = the faster of the two, measured per scene
 int g_refine_leaf = 2;        // qd_set_kd_refine
 double g_refine_cost = 0.6;
-int g_kd_build = 1;           // qd_set_kd_build: 0 = the caller's planes, leaves refined; 1 = whole tree by the surface-area heuristic
+int g_kd_build = 1;           // qd_set_kd_build: 0 = the caller's planes, leaves refined; 1 = whole tree by the surface-area heuristic, built on the device (kdbuild.h); 2 = the same by host threads (kdrefine.h)
 
 int set_err(const std::string& m) { g_err = m; return -1; }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
@@ -1414,7 +1415,7 @@ extern "C" void qd_shutdown(void) { g_device = -1; }
 extern "C" int qd_set_counting(int on) { g_counting = on != 0; return 0; }
 
 extern "C" int qd_set_kd_build(int mode) {
-    if (mode != 0 && mode != 1) return set_err("qd_set_kd_build: 0 (the caller's planes, leaves refined) or 1 (whole tree by the surface-area heuristic)");
+    if (mode < 0 || mode > 2) return set_err("qd_set_kd_build: 0 (the caller's planes, leaves refined), 1 (whole tree by the surface-area heuristic, built on the device) or 2 (the same, built by host threads)");
     g_kd_build = mode;
     return 0;
 }
@@ -1579,32 +1580,73 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     int rc = 0;
     rc |= upload(s, desc->nodes, desc->n_nodes, &d.nodes);
     rc |= upload(s, desc->geoms, desc->n_geoms, &d.geoms);
-    std::vector<qd_refine::Record> kd_records;
     std::vector<qd_mesh> meshes_dev(desc->meshes, desc->meshes + desc->n_meshes);
-    std::vector<uint32_t> leaf_global;       // leaf references as GLOBAL triangle indices
-    {
+    auto wants_tree = [](const qd_mesh& m) { return m.kd_root >= 0 || (m.flags & QD_MESH_WANT_KD) != 0; };
+    rc |= upload(s, desc->tri_verts, (size_t)desc->n_tris * 9, &d.tri_verts);
+    size_t n_leaf_refs = 0;
+    const bool device_build = g_kd_build == 1 && g_refine_leaf > 0;
+    if (!rc && device_build) {
+        // the device KD trees, built on the device from the triangles just uploaded (kdbuild.h)
+        const auto t_build0 = std::chrono::steady_clock::now();
+        qd_kdbuild::Opt opt;
+        opt.max_leaf = g_refine_leaf; opt.cost_step = g_refine_cost; opt.max_depth = kKdStack - 2; opt.binned_above = 192;
+        qd_kdbuild::Trees T;
+        for (size_t mi = 0; mi < meshes_dev.size() && !rc; ++mi) {
+            if (!wants_tree(meshes_dev[mi])) continue;
+            uint32_t root = 0;
+            const std::string err = qd_kdbuild::build_mesh(d.tri_verts, meshes_dev[mi], opt, T, &root);
+            if (!err.empty()) { rc = set_err("qd_scene_create: device KD build: " + err); break; }
+            meshes_dev[mi].kd_root = (int32_t)root;
+        }
+        if (!rc) {
+            s->kd_nodes = T.n_nodes; s->kd_refs = T.n_refs; s->kd_leaves = T.leaves; s->kd_max_leaf = T.max_leaf;
+            n_leaf_refs = (size_t)T.n_refs;
+            if (hipDeviceSynchronize() != hipSuccess) rc = set_err("qd_scene_create: device KD build failed");
+            void* recs = T.records.release(); void* refs = T.leaf_refs.release();
+            if (recs) s->allocs.push_back(recs);
+            if (refs) s->allocs.push_back(refs);
+            d.kd_nodes = (const qd_kdnode*)recs; d.leaf_tris = (const uint32_t*)refs;
+        }
+        s->t_kd_build = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build0).count();
+    } else if (!rc) {
+        // the device KD trees built by the host cores (kdrefine.h): the caller's planes with refined leaves (mode 0), or the
+        // whole tree by the same heuristic as the device builder (mode 2)
+        for (const qd_mesh& m : meshes_dev)
+            if (m.kd_root < 0 && (m.flags & QD_MESH_WANT_KD) && !(g_kd_build == 2 && g_refine_leaf > 0)) {
+                qd_scene_destroy(s);
+                return set_err("qd_scene_create: qd_set_kd_build(0) / qd_set_kd_refine(0, .) need the caller's KD tree, and this scene description "
+                               "has none (libqdhost builds it on request: qdh_scene_build_kd)");
+            }
+        for (qd_mesh& m : meshes_dev) if (m.kd_root < 0 && (m.flags & QD_MESH_WANT_KD)) m.kd_root = 0;     // mode 2 ignores the caller's tree
+        std::vector<qd_refine::Record> kd_records;
+        std::vector<uint32_t> leaf_global;       // leaf references as GLOBAL triangle indices
+        qd_scene_desc view = *desc;
+        view.meshes = meshes_dev.data();
         qd_refine::Options opt;
         opt.max_leaf = g_refine_leaf;
         opt.cost_step = g_refine_cost;
         opt.max_depth = kKdStack - 2;
-        opt.rebuild = g_kd_build == 1 && g_refine_leaf > 0;
+        opt.rebuild = g_kd_build != 0 && g_refine_leaf > 0;
         qd_refine::Result refined;
         const auto t_build0 = std::chrono::steady_clock::now();
-        const std::string err = qd_refine::refine(desc, opt, refined);
-        if (!err.empty()) { delete s; return set_err("qd_scene_create: " + err); }
-        if (refined.n_refs >= (1ull << 32) || refined.n_nodes >= (1ull << 27)) { delete s; return set_err("qd_scene_create: KD tree too large for the 28-bit record index"); }
+        const std::string err = qd_refine::refine(&view, opt, refined);
+        if (!err.empty()) { qd_scene_destroy(s); return set_err("qd_scene_create: " + err); }
+        if (refined.n_refs >= (1ull << 32) || refined.n_nodes >= (1ull << 27)) { qd_scene_destroy(s); return set_err("qd_scene_create: KD tree too large for the 28-bit record index"); }
         leaf_global.reserve(refined.n_refs);
         for (size_t mi = 0; mi < meshes_dev.size(); ++mi) {
             const qd_refine::MeshTree& T = refined.trees[mi];
-            if (T.nodes.empty()) continue;
+            if (T.nodes.empty()) { meshes_dev[mi].kd_root = -1; continue; }
             meshes_dev[mi].kd_root = (int32_t)qd_refine::pack(T, kd_records, leaf_global.size());
             for (uint32_t t : T.refs) leaf_global.push_back(t + meshes_dev[mi].tri_first);
         }
         s->kd_nodes = refined.n_nodes; s->kd_refs = refined.n_refs; s->kd_leaves = refined.leaves; s->kd_max_leaf = refined.max_leaf;
         s->t_kd_build = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build0).count();
+        if (kd_records.size() >= (1u << 28)) { qd_scene_destroy(s); return set_err("qd_scene_create: KD tree too large for the 28-bit record index"); }
+        { const qd_refine::Record* recs = nullptr; rc |= upload(s, kd_records.data(), kd_records.size(), &recs); d.kd_nodes = (const qd_kdnode*)recs; }
+        rc |= upload(s, leaf_global.data(), leaf_global.size(), &d.leaf_tris);
+        n_leaf_refs = leaf_global.size();
     }
     const auto t_upload0 = std::chrono::steady_clock::now();
-    if (kd_records.size() >= (1u << 28)) { delete s; return set_err("qd_scene_create: KD tree too large for the 28-bit record index"); }
     rc |= upload(s, meshes_dev.data(), meshes_dev.size(), &d.meshes);
     rc |= upload(s, desc->hfields, desc->n_hfields, &d.hfields);
     rc |= upload(s, desc->shaders, desc->n_shaders, &d.shaders);
@@ -1613,13 +1655,10 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     rc |= upload(s, desc->proc_lines, desc->n_proc_lines, &d.proc_lines);
     rc |= upload(s, desc->bitmaps, desc->n_bitmaps, &d.bitmaps);
     rc |= upload(s, desc->lights, desc->n_lights, &d.lights);
-    rc |= upload(s, desc->tri_verts, (size_t)desc->n_tris * 9, &d.tri_verts);
     rc |= upload(s, desc->tri_gnormal, (size_t)desc->n_tris * 3, &d.tri_gnormal);
     rc |= upload(s, desc->tri_shade, (size_t)desc->n_tris * 21, &d.tri_shade);
-    { const qd_refine::Record* recs = nullptr; rc |= upload(s, kd_records.data(), kd_records.size(), &recs); d.kd_nodes = (const qd_kdnode*)recs; }
-    rc |= upload(s, leaf_global.data(), leaf_global.size(), &d.leaf_tris);
     if (!rc) {
-        const size_t n_words = leaf_global.size() * 9;
+        const size_t n_words = n_leaf_refs * 9;
         void* lv = nullptr;
         if (hipMalloc(&lv, (n_words ? n_words : 1) * sizeof(double) + 256) != hipSuccess) rc = set_err("hipMalloc(leaf_verts) failed");
         else {

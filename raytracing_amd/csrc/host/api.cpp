@@ -36,6 +36,14 @@ extern "C" void qdh_set_prep_hooks(const qdh_prep_hooks* hooks) {
 extern "C" int qdh_prep_hook_calls(void) { return qdh::g_prep_hook_calls + qdh::g_differentiate_hook_calls; }
 
 extern "C" qd_scene_desc* qdh_scene_desc(qdh_scene* s) { return s ? &s->impl.desc : nullptr; }
+
+extern "C" void qdh_set_eager_kd(int on) { qdh::g_eager_kd = on != 0; }
+
+extern "C" int qdh_scene_build_kd(qdh_scene* s) {
+    if (!s) { g_err = "qdh_scene_build_kd: null scene"; return -1; }
+    s->impl.build_kd();
+    return 0;
+}
 extern "C" void qdh_free_scene(qdh_scene* s) { delete s; }
 extern "C" void qdh_free(void* p) { free(p); }
 
@@ -156,10 +164,11 @@ extern "C" qdh_scene* qdh_synth_scene(int n, unsigned seed, int width, int heigh
     std::unique_ptr<MeshData> m(new MeshData);
     m->faceted = false; m->backcull = false; m->use_kd = true; m->use_sah = false;
     const size_t nv = (size_t)(n + 1) * (n + 1);
-    m->verts.assign(1, V3()); m->normals.assign(1, V3()); m->uvs.assign(1, V3());
-    m->verts.reserve(nv + 1); m->normals.reserve(nv + 1); m->uvs.reserve(nv + 1);
-    for (int j = 0; j <= n; ++j)
+    m->verts.assign(nv + 1, V3()); m->normals.assign(nv + 1, V3()); m->uvs.assign(nv + 1, V3());
+    parallel_for((size_t)n + 1, [&](size_t j0, size_t j1) {
+    for (int j = (int)j0; j < (int)j1; ++j)
         for (int i = 0; i <= n; ++i) {
+            const size_t at = 1 + (size_t)j * (n + 1) + i;
             const double x = -1.0 + 2.0 * i / n, z = -1.0 + 2.0 * j / n;
             double h = 0, dhx = 0, dhz = 0;
             for (int k = 0; k < OCT; ++k) {
@@ -169,21 +178,24 @@ extern "C" qdh_scene* qdh_synth_scene(int n, unsigned seed, int width, int heigh
                 dhx += amp[k] * fx[k] * cx * sz;
                 dhz += amp[k] * fz[k] * sx * cz;
             }
-            m->verts.emplace_back(x, h, z);
-            m->normals.push_back(normalized(V3(-dhx, 1.0, -dhz)));
-            m->uvs.emplace_back((double)i, (double)j, 0.0);
+            m->verts[at] = V3(x, h, z);
+            m->normals[at] = normalized(V3(-dhx, 1.0, -dhz));
+            m->uvs[at] = V3((double)i, (double)j, 0.0);
         }
-    m->tris.reserve((size_t)2 * n * n);
+    }, 256);
+    m->tris.resize((size_t)2 * n * n);
     auto vid = [&](int i, int j) { return 1 + j * (n + 1) + i; };
-    for (int j = 0; j < n; ++j)
+    parallel_for((size_t)n, [&](size_t j0, size_t j1) {
+    for (int j = (int)j0; j < (int)j1; ++j)
         for (int i = 0; i < n; ++i) {
             const int a = vid(i, j), b = vid(i + 1, j), c = vid(i + 1, j + 1), d = vid(i, j + 1);
             MeshTri t1{}, t2{};
             // counter-clockwise seen from +y so geometric normals point up
             const int q1[3] = {a, d, b}, q2[3] = {b, d, c};
             for (int k = 0; k < 3; ++k) { t1.v[k] = t1.n[k] = t1.t[k] = q1[k]; t2.v[k] = t2.n[k] = t2.t[k] = q2[k]; }
-            m->tris.push_back(t1); m->tris.push_back(t2);
+            m->tris[((size_t)j * n + i) * 2] = t1; m->tris[((size_t)j * n + i) * 2 + 1] = t2;
         }
+    }, 256);
     m->generate_triangle_data();
     S.mesh_src.push_back(std::move(m));
 

@@ -207,7 +207,9 @@ bool MeshData::load_obj(const char* path, std::string& err) {
 }
 
 void MeshData::generate_triangle_data() {
-    for (MeshTri& t : tris) {
+    parallel_for(tris.size(), [&](size_t b0, size_t e0) {
+    for (size_t i = b0; i < e0; ++i) {
+        MeshTri& t = tris[i];
         const V3& a = verts[t.v[0]]; const V3& b = verts[t.v[1]]; const V3& c = verts[t.v[2]];
         const V3 ab = b - a, ac = c - a;
         t.gnormal = normalized(cross(ab, ac));
@@ -219,18 +221,22 @@ void MeshData::generate_triangle_data() {
         t.dNdx = normalized(px * ab + qx * ac);
         t.dNdy = normalized(py * ab + qy * ac);
     }
+    });
 }
 
-void MeshData::begin_render() {
+void MeshData::compute_bounds() {
     bmin = V3(kInf, kInf, kInf);
     bmax = V3(-kInf, -kInf, -kInf);
     for (const V3& v : verts) {      // includes the dummy vertex 0
         bmin.x = std::min(bmin.x, v.x); bmin.y = std::min(bmin.y, v.y); bmin.z = std::min(bmin.z, v.z);
         bmax.x = std::max(bmax.x, v.x); bmax.y = std::max(bmax.y, v.y); bmax.z = std::max(bmax.z, v.z);
     }
+}
+
+void MeshData::build_kd() {
     kd.clear(); leaf_tris.clear();
     kd_max_depth = kd_leaves = 0; kd_depth_sum = kd_leaf_tri_sum = 0;
-    if (!use_kd || tris.size() < 50) return;     // src/mesh.cpp:200
+    if (!wants_kd()) return;
     Builder b(*this);
     std::vector<uint32_t> all(tris.size());
     for (size_t i = 0; i < all.size(); ++i) all[i] = (uint32_t)i;

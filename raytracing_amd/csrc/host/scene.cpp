@@ -570,59 +570,53 @@ SceneImpl::SceneImpl() {
     for (int i = 0; i < 6; ++i) desc.env_faces[i] = -1;
 }
 
-// Scene::BeginRender part: mesh bbox + KD, highmap; then publish flat arrays.
+bool g_eager_kd = false;
+
+// Scene::BeginRender part: mesh bbox, triangle arrays, highmap; then publish flat arrays.  The KD trees of the meshes
+// (Mesh::BuildKD) are built by build_kd(), on request.
 void SceneImpl::finalize() {
     meshes.clear(); tri_verts.clear(); tri_gnormal.clear(); tri_shade.clear(); kd_nodes.clear(); leaf_tris.clear();
+    kd_built = false;
+    size_t total = 0;
+    for (auto& mp : mesh_src) total += mp->tris.size();
+    tri_verts.resize(total * 9); tri_gnormal.resize(total * 3); tri_shade.resize(total * 21);
+    size_t first = 0;
     for (auto& mp : mesh_src) {
         MeshData& m = *mp;
-        m.begin_render();
+        m.compute_bounds();
         qd_mesh qm{};
-        qm.tri_first = (uint32_t)(tri_verts.size() / 9);
+        qm.tri_first = (uint32_t)first;
         qm.tri_count = (uint32_t)m.tris.size();
-        qm.flags = (m.faceted ? QD_MESH_FACETED : 0) | (m.backcull ? QD_MESH_BACKCULL : 0);
+        qm.flags = (m.faceted ? QD_MESH_FACETED : 0) | (m.backcull ? QD_MESH_BACKCULL : 0) | (m.wants_kd() ? QD_MESH_WANT_KD : 0);
         qm.bbox_min[0] = m.bmin.x; qm.bbox_min[1] = m.bmin.y; qm.bbox_min[2] = m.bmin.z;
         qm.bbox_max[0] = m.bmax.x; qm.bbox_max[1] = m.bmax.y; qm.bbox_max[2] = m.bmax.z;
-        qm.kd_max_depth = m.kd_max_depth; qm.kd_leaves = m.kd_leaves;
-        qm.kd_depth_sum = m.kd_depth_sum; qm.kd_leaf_tris = m.kd_leaf_tri_sum;
-        tri_verts.reserve(tri_verts.size() + m.tris.size() * 9);
-        tri_gnormal.reserve(tri_gnormal.size() + m.tris.size() * 3);
-        tri_shade.reserve(tri_shade.size() + m.tris.size() * 21);
-        for (const MeshTri& t : m.tris) {
-            const V3& A = m.verts[t.v[0]]; const V3& B = m.verts[t.v[1]]; const V3& C = m.verts[t.v[2]];
-            const V3 ab = B - A, ac = C - A;
-            const double tv[9] = {A.x, A.y, A.z, ab.x, ab.y, ab.z, ac.x, ac.y, ac.z};
-            tri_verts.insert(tri_verts.end(), tv, tv + 9);
-            const double gn[3] = {t.gnormal.x, t.gnormal.y, t.gnormal.z};
-            tri_gnormal.insert(tri_gnormal.end(), gn, gn + 3);
-            double sh[21];
-            for (int k = 0; k < 3; ++k) {
-                const V3& n = m.normals[t.n[k]];
-                sh[k * 3 + 0] = n.x; sh[k * 3 + 1] = n.y; sh[k * 3 + 2] = n.z;
-                const V3& uv = m.uvs[t.t[k]];
-                sh[9 + k * 2 + 0] = uv.x; sh[9 + k * 2 + 1] = uv.y;
+        qm.kd_root = -1;
+        const size_t n = m.tris.size();
+        auto fill = [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                const MeshTri& t = m.tris[i];
+                const V3& A = m.verts[t.v[0]]; const V3& B = m.verts[t.v[1]]; const V3& C = m.verts[t.v[2]];
+                const V3 ab = B - A, ac = C - A;
+                double* tv = &tri_verts[(first + i) * 9];
+                tv[0] = A.x; tv[1] = A.y; tv[2] = A.z; tv[3] = ab.x; tv[4] = ab.y; tv[5] = ab.z; tv[6] = ac.x; tv[7] = ac.y; tv[8] = ac.z;
+                double* gn = &tri_gnormal[(first + i) * 3];
+                gn[0] = t.gnormal.x; gn[1] = t.gnormal.y; gn[2] = t.gnormal.z;
+                double* sh = &tri_shade[(first + i) * 21];
+                for (int k = 0; k < 3; ++k) {
+                    const V3& nn = m.normals[t.n[k]];
+                    sh[k * 3 + 0] = nn.x; sh[k * 3 + 1] = nn.y; sh[k * 3 + 2] = nn.z;
+                    const V3& uv = m.uvs[t.t[k]];
+                    sh[9 + k * 2 + 0] = uv.x; sh[9 + k * 2 + 1] = uv.y;
+                }
+                sh[15] = t.dNdx.x; sh[16] = t.dNdx.y; sh[17] = t.dNdx.z;
+                sh[18] = t.dNdy.x; sh[19] = t.dNdy.y; sh[20] = t.dNdy.z;
             }
-            sh[15] = t.dNdx.x; sh[16] = t.dNdx.y; sh[17] = t.dNdx.z;
-            sh[18] = t.dNdy.x; sh[19] = t.dNdy.y; sh[20] = t.dNdy.z;
-            tri_shade.insert(tri_shade.end(), sh, sh + 21);
-        }
-        if (m.kd.empty()) qm.kd_root = -1;
-        else {
-            // rebase mesh-local node / leaf indices into the global arrays
-            const uint32_t node_base = (uint32_t)kd_nodes.size();
-            const uint32_t leaf_base = (uint32_t)leaf_tris.size();
-            qm.kd_root = (int32_t)node_base;
-            for (qd_kdnode n : m.kd) {
-                const uint32_t axis = n.meta & 3u, idx = n.meta >> 2;
-                n.meta = ((idx + (axis == 3 ? leaf_base : node_base)) << 2) | axis;
-                kd_nodes.push_back(n);
-            }
-            leaf_tris.insert(leaf_tris.end(), m.leaf_tris.begin(), m.leaf_tris.end());
-        }
+        };
+        parallel_for(n, fill);
+        first += n;
         meshes.push_back(qm);
-        // the flat arrays now hold everything the trace path needs; drop the builder's copies
-        std::vector<qd_kdnode>().swap(m.kd);
-        std::vector<uint32_t>().swap(m.leaf_tris);
     }
+    if (g_eager_kd) build_kd_arrays();
 
     hfields.clear(); hf_f32.clear(); hf_f64.clear();
     for (auto& hp : hf_src) {
@@ -639,6 +633,42 @@ void SceneImpl::finalize() {
         for (const V3& n : h.normals) { hf_f64.push_back(n.x); hf_f64.push_back(n.y); hf_f64.push_back(n.z); }
         hfields.push_back(q);
     }
+    publish();
+}
+
+// The reference-shaped trees (midpoint / "SAH" planes, 20 triangles per leaf): node and leaf arrays of all meshes, rebased.
+void SceneImpl::build_kd_arrays() {
+    kd_nodes.clear(); leaf_tris.clear();
+    for (size_t mi = 0; mi < mesh_src.size(); ++mi) {
+        MeshData& m = *mesh_src[mi];
+        qd_mesh& qm = meshes[mi];
+        m.build_kd();
+        qm.kd_max_depth = m.kd_max_depth; qm.kd_leaves = m.kd_leaves;
+        qm.kd_depth_sum = m.kd_depth_sum; qm.kd_leaf_tris = m.kd_leaf_tri_sum;
+        if (m.kd.empty()) qm.kd_root = -1;
+        else {
+            // rebase mesh-local node / leaf indices into the global arrays
+            const uint32_t node_base = (uint32_t)kd_nodes.size();
+            const uint32_t leaf_base = (uint32_t)leaf_tris.size();
+            qm.kd_root = (int32_t)node_base;
+            kd_nodes.reserve(kd_nodes.size() + m.kd.size());
+            for (qd_kdnode n : m.kd) {
+                const uint32_t axis = n.meta & 3u, idx = n.meta >> 2;
+                n.meta = ((idx + (axis == 3 ? leaf_base : node_base)) << 2) | axis;
+                kd_nodes.push_back(n);
+            }
+            leaf_tris.insert(leaf_tris.end(), m.leaf_tris.begin(), m.leaf_tris.end());
+        }
+        // the flat arrays now hold everything the trace path needs; drop the builder's copies
+        std::vector<qd_kdnode>().swap(m.kd);
+        std::vector<uint32_t>().swap(m.leaf_tris);
+    }
+    kd_built = true;
+}
+
+void SceneImpl::build_kd() {
+    if (kd_built) return;
+    build_kd_arrays();
     publish();
 }
 

@@ -22,7 +22,7 @@ struct SceneImpl {
     std::vector<qd_proc_line> proc_lines;
     std::vector<qd_bitmap> bitmaps;
     std::vector<qd_light> lights;
-    std::vector<double> tri_verts, tri_gnormal, tri_shade;
+    raw_vector<double> tri_verts, tri_gnormal, tri_shade;       // filled on all cores by finalize()
     std::vector<qd_kdnode> kd_nodes;
     std::vector<uint32_t> leaf_tris;
     std::vector<float> texels;
@@ -36,8 +36,14 @@ struct SceneImpl {
     SceneImpl();
     bool load(const char* path, std::string& err);
     bool load_env(const std::string& folder, bool bilinear, std::string& err);
-    void finalize();   // BeginRender: bbox + KD build + highmap, then publish()
+    bool kd_built = false;
+    void finalize();   // BeginRender: bbox + highmap (+ the KD trees when g_eager_kd), then publish()
+    void build_kd();   // the reference-shaped KD trees of the meshes (Mesh::BuildKD), on request: the device builds its own tree
+                       // from the triangles, so only the CPU oracle and qd_set_kd_build(0) read these
     void publish();    // point desc at the vectors
+    void build_kd_arrays();
 };
+
+extern bool g_eager_kd;     // qdh_set_eager_kd: build the KD trees inside qdh_load_scene, as Scene::BeginRender does
 
 }  // namespace qdh

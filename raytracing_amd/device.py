@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 _LIB_OVERRIDE = None          # development only: scripts/ A/B another build of the same kernels through use_library()
 _INIT_DEVICE = None
+_KD_BUILD, _KD_REFINE_LEAF = 1, 2       # what qd_set_kd_build / qd_set_kd_refine were last given (DeviceScene: does the library need the caller's tree?)
 SETTLE_FRAMES = 6            # lone frames after which the adaptive choice of the scheduling form has both figures (2 per form + 2 to average)
 
 
@@ -109,8 +110,11 @@ def set_counting(on):
 
 
 def set_kd_build(mode):
-    """Device KD tree of scenes created afterwards: 1 = whole tree by the surface-area heuristic, 0 = the caller's planes with refined leaves."""
+    """Device KD tree of scenes created afterwards: 1 = whole tree by the surface-area heuristic, built on the device (default);
+    2 = the same tree built by host threads; 0 = the caller's planes with refined leaves."""
+    global _KD_BUILD
     _check(lib().qd_set_kd_build(mode), "qd_set_kd_build")
+    _KD_BUILD = mode
 
 
 def set_pipeline(pipeline):
@@ -121,7 +125,9 @@ def set_pipeline(pipeline):
 
 def set_kd_refine(max_leaf_tris=2, step_cost=0.6):
     """Leaf refinement of the device copy of KD trees for scenes created afterwards (0 = caller's tree unchanged)."""
+    global _KD_REFINE_LEAF
     _check(lib().qd_set_kd_refine(max_leaf_tris, step_cost), "qd_set_kd_refine")
+    _KD_REFINE_LEAF = max_leaf_tris
 
 
 class DeviceScene:
@@ -131,6 +137,8 @@ class DeviceScene:
         if _INIT_DEVICE is None:
             init(0)
         self.host_scene = scene
+        if (_KD_BUILD == 0 or _KD_REFINE_LEAF <= 0) and hasattr(scene, "ensure_kd"):
+            scene.ensure_kd()          # these modes start from the caller's (reference-shaped) tree, which the front end builds on request
         h = C.c_void_p()
         _check(lib().qd_scene_create(scene.desc_ptr, C.byref(h)), "qd_scene_create")
         self._h = h

@@ -24,6 +24,10 @@ def lib():
         L.qdh_scene_desc.restype = C.POINTER(abi.QdSceneDesc)
         L.qdh_scene_desc.argtypes = [C.c_void_p]
         L.qdh_free_scene.argtypes = [C.c_void_p]
+        L.qdh_scene_build_kd.restype = C.c_int
+        L.qdh_scene_build_kd.argtypes = [C.c_void_p]
+        L.qdh_set_eager_kd.restype = None
+        L.qdh_set_eager_kd.argtypes = [C.c_int]
         L.qdh_last_error.restype = C.c_char_p
         L.qdh_camera_corners.argtypes = [C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double, C.c_double,
                                          C.c_double, C.POINTER(abi.QdCamera)]
@@ -94,7 +98,15 @@ class Scene:
     def camera(self):
         return self.desc.camera
 
+    def ensure_kd(self):
+        """The reference-shaped KD trees of the meshes (qdh_scene_build_kd): built on first request.  The device library
+        builds its own tree from the triangles and does not need them; the CPU oracle and qd_set_kd_build(0) do."""
+        if lib().qdh_scene_build_kd(self._h) != 0:
+            raise SceneError(lib().qdh_last_error().decode())
+        return self
+
     def kd_stats(self, mesh=0):
+        self.ensure_kd()
         m = self.desc.meshes[mesh]
         leaves = m.kd_leaves
         return {"triangles": m.tri_count, "max_depth": m.kd_max_depth, "leaves": leaves,

@@ -38,6 +38,7 @@ int main(int argc, char** argv) {
     qdh_scene* hs = std::strncmp(argv[1], "synth:", 6) == 0 ? qdh_synth_scene(std::atoi(argv[1] + 6), 42, 640, 360, 8, nullptr) : qdh_load_scene(argv[1]);
     const bool rebuild = argc > 5 && std::atoi(argv[5]) != 0, do_brute = !(argc > 6 && std::atoi(argv[6]) == 0), cam = argc > 7 && std::atoi(argv[7]) != 0;
     if (!hs) { std::printf("load failed: %s\n", qdh_last_error()); return 2; }
+    if (qdh_scene_build_kd(hs) != 0) { std::printf("kd build failed: %s\n", qdh_last_error()); return 2; }     // the caller's tree (refine() wants a root even when it rebuilds)
     const qd_scene_desc* d = qdh_scene_desc(hs);
     qd_refine::Options opt; opt.max_leaf = std::atoi(argv[3]); opt.cost_step = std::atof(argv[4]); opt.rebuild = rebuild;
     qd_refine::Result R;

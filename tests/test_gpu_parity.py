@@ -455,6 +455,64 @@ def test_full_aa_and_bucket_border_dependency(load_scene):
 
 
 # ---------------------------------------------------------------- device KD tree options
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["kdtree_fixed.qdmg", "hw9/dragon.qdmg", "kdtree_teapot_hires_sah_noenv.qdmg", "synth:330"])
+def test_device_built_tree_equals_the_host_built_tree(load_scene, data_dir, name):
+    """qd_set_kd_build(1), the default, builds the device KD tree with HIP kernels (kdbuild.h), a level
+    per round; qd_set_kd_build(2) builds it with host threads (kdrefine.h) by the same rules.  Below 524 288 triangles
+    (where the host builder starts to bin a sample) both must give the SAME tree: node, leaf and reference counts and
+    the largest leaf equal, node visits and triangle tests of a counted frame equal, hits equal to the bit.  The scenes
+    cover binned planes (dragon: 100 k triangles), the exact sweep with one wave and with eight lanes per node, a mesh
+    whose triangles overlap heavily (teapot_hires) and the description without a caller's tree (synth: QD_MESH_WANT_KD)."""
+    if name.startswith("synth:"):
+        s = host.Scene.synthetic(int(name[6:]), seed=42, width=640, height=360, max_trace_depth=4, env_folder=os.path.join(data_dir, "env", "forest"))
+        assert s.desc.meshes[0].kd_root == -1 and s.desc.n_kd_nodes == 0          # no tree from the front end: the device makes its own
+    else:
+        s = load_scene(name)
+    old = _aa_settings(s, want_aa=0)
+    out = {}
+    try:
+        for mode in (1, 2):
+            device.set_kd_build(mode)
+            ds = device.DeviceScene(s)
+            try:
+                device.set_counting(True)
+                rgb, hits, st = ds.render(hits=True)
+                out[mode] = (ds.kd_info(), st, hits, rgb, ds.setup_info())
+            finally:
+                device.set_counting(False)
+                ds.close()
+    finally:
+        device.set_kd_build(1)
+        _aa_settings(s, **old)
+    (ia, sa, ha, ra, ta), (ib, sb, hb, rb, tb) = out[1], out[2]
+    print(f"{name}: device-built {ia} in {ta['kd_build_s'] * 1e3:.1f} ms, host-built {ib} in {tb['kd_build_s'] * 1e3:.1f} ms")
+    assert ia == ib and ia["nodes"] > 1000
+    assert sa["kd_nodes_visited"] == sb["kd_nodes_visited"] and sa["tris_tested"] == sb["tris_tested"] and sa["rays"] == sb["rays"]
+    assert np.array_equal(ha[0], hb[0]) and np.array_equal(ha[1], hb[1]) and np.array_equal(ha[2].view(np.uint64), hb[2].view(np.uint64))
+    assert np.abs(ra - rb).max() <= 5e-5          # float additions in a different order (a 25-sample glossy floor sums 26 terms per pixel)
+
+
+@pytest.mark.gpu
+def test_callers_tree_modes_need_the_callers_tree(data_dir):
+    """qd_set_kd_build(0) and qd_set_kd_refine(0, .) start from the caller's tree; a description without one (libqdhost
+    builds its reference-shaped tree on request only) is refused with a message that says what to call."""
+    s = host.Scene.synthetic(24, seed=42, width=64, height=36, max_trace_depth=2)
+    assert s.desc.meshes[0].kd_root == -1
+    import ctypes as C
+    device.init(0)
+    L = device.lib()
+    h = C.c_void_p()
+    try:
+        assert L.qd_set_kd_build(0) == 0
+        assert L.qd_scene_create(s.desc_ptr, C.byref(h)) != 0 and b"qdh_scene_build_kd" in L.qd_last_error()
+        s.ensure_kd()
+        assert L.qd_scene_create(s.desc_ptr, C.byref(h)) == 0
+        L.qd_scene_destroy(h)
+    finally:
+        L.qd_set_kd_build(1)
+
+
 def test_callers_tree_refined_tree_and_rebuilt_tree_give_the_same_hits(load_scene):
     """qd_set_kd_refine(0, .) walks the caller's leaves (up to 19 triangles each); qd_set_kd_build(0) keeps the caller's
     planes and splits the leaves further; qd_set_kd_build(1), the default, builds the device tree from the triangles by

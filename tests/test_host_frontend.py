@@ -37,7 +37,7 @@ def test_mesh_bbox_includes_the_dummy_origin_vertex(load_scene):
 
 
 def test_kd_tree_is_well_formed(load_scene):
-    d = load_scene("kdtree_teapot_lowres_noenv.qdmg").desc
+    d = load_scene("kdtree_teapot_lowres_noenv.qdmg").ensure_kd().desc
     nodes = np.ctypeslib.as_array(C_cast(d.kd_nodes, d.n_kd_nodes * 4, "u4"), shape=(d.n_kd_nodes * 4,)).reshape(-1, 4)
     meta, count = nodes[:, 2], nodes[:, 3]
     axis, idx = meta & 3, meta >> 2
@@ -227,7 +227,10 @@ def test_synthetic_scene_is_reproducible():
     vb = np.ctypeslib.as_array(b.desc.tri_verts, shape=(b.desc.n_tris * 9,))
     vc = np.ctypeslib.as_array(c.desc.tri_verts, shape=(c.desc.n_tris * 9,))
     assert a.desc.n_tris == 2 * 16 * 16 and np.array_equal(va, vb) and not np.array_equal(va, vc)
-    assert a.desc.meshes[0].kd_root >= 0 and a.settings.max_trace_depth == 3
+    assert a.settings.max_trace_depth == 3
+    # the reference-shaped tree is built on request (the device builds its own from the triangles)
+    assert a.desc.meshes[0].kd_root == -1 and a.desc.meshes[0].flags & 4 and a.desc.n_kd_nodes == 0
+    assert a.ensure_kd().desc.meshes[0].kd_root >= 0 and a.desc.n_kd_nodes > 0 and a.desc.n_leaf_tris >= a.desc.n_tris
 
 
 @pytest.mark.parametrize("n", [96, 2240])

@@ -81,7 +81,7 @@ def test_kd_walk_equals_brute_force(load_scene, tmp_path, data_dir):
     finally:
         os.remove(p)
     kd = load_scene("kdtree_teapot_lowres_noenv.qdmg")
-    assert brute.desc.meshes[0].kd_root == -1 and kd.desc.meshes[0].kd_root >= 0
+    assert brute.ensure_kd().desc.meshes[0].kd_root == -1 and kd.ensure_kd().desc.meshes[0].kd_root >= 0
     a, ha, _ = oracle.render_rect(kd, 400, 300, 800, 600, hits=True, threads=8)
     b, hb, _ = oracle.render_rect(brute, 400, 300, 800, 600, hits=True, threads=8)
     assert np.array_equal(ha[0], hb[0]) and np.array_equal(ha[1], hb[1]) and np.array_equal(ha[2].view(np.uint64), hb[2].view(np.uint64))
