@@ -27,6 +27,33 @@ if int(os.environ.get("GPU_MAX_HW_QUEUES") or 0) < 8:
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_PEAK_GBS = 34500.0     # MI355X_MICROARCH.md: L2, 4 MiB per XCD, ~34.5 TB/s aggregate
+MAX_CLOCK_HZ = 2.4e9      # MI355X_MICROARCH.md: max clock (the chip holds less under load: the issue bound below is priced on the maximum)
+
+
+def lib_sha256():
+    import hashlib
+    from raytracing_amd import device
+    path = device._LIB_OVERRIDE or os.path.join(ROOT, "raytracing_amd", "lib", "libqdtrace.so")
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
+def profiled_counters(key):
+    """PMC sums per frame of a separate `rocprofv3 --pmc` run of this workload (scripts/gpu_profile.sh ->
+    scripts/update_traffic.py -> profiles/hbm_traffic.json), valid only for the library build they were collected on:
+    (entry or None, source string)."""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not key or not os.path.exists(tpath):
+        return None, "no PMC profile of this workload under profiles/"
+    try:
+        e = json.load(open(tpath)).get(key)
+    except Exception as ex:
+        return None, f"profiles/hbm_traffic.json unreadable: {ex}"
+    if not e:
+        return None, "no PMC profile of this workload under profiles/"
+    if e.get("lib_sha256") != lib_sha256():
+        return None, f"stale: profiles/hbm_traffic.json[{key}] was collected on build {e.get('build')} (another libqdtrace.so than this run's)"
+    return e, f"profiles/hbm_traffic.json[{key}], build {e.get('build')}, libqdtrace.so sha256 {e['lib_sha256'][:12]}: {e.get('source', '')}"
 
 
 def build_scene(args):
@@ -83,6 +110,46 @@ def cpu_baseline(scene, budget_s=12.0, gpu_frame=None):
     return out, parity
 
 
+def leg_1080p(args, scene, fr, rank, world, local, barrier):
+    """The scene of the timed region once more at 1920x1080 (same camera, same device scene and form choice, same frames in
+    flight): ms per frame and whole-job rays/s.  Untimed as far as `value` goes."""
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import device, renderer
+    st = scene.settings
+    old = (st.frame_width, st.frame_height)
+    if args.pipeline is None or args.pipeline == 2:
+        device.set_pipeline(2)                                    # the library's own choice, as in the timed region
+    st.frame_width, st.frame_height = 1920, 1080
+    try:
+        f2 = renderer.FrameRenderer(scene, tile=args.tile, rank=rank, world=world, local_device=local, frames_in_flight=args.frames_in_flight,
+                                    dscene=fr.dscene, comm=fr.comm, streams=[sl.stream for sl in fr.slots])
+        f2.settle()
+        barrier()
+        for _ in range(args.warmup):
+            f2.submit_frame()
+        barrier()
+        f2.check()
+        steps = max(args.steps, 20)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            f2.submit_frame()
+        barrier()
+        dt = time.perf_counter() - t0
+        f2.check()
+        sched = f2.dscene.schedule_info()
+        v = torch.tensor([float(f2.stats_dict()["rays"]), dt], dtype=torch.float64)
+        if world > 1:
+            r = v[:1].clone(); t = v[1:].clone()
+            dist.all_reduce(r, op=dist.ReduceOp.SUM); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            v = torch.cat([r, t])
+        rays, dt = float(v[0].item()), float(v[1].item())
+        return {"width": 1920, "height": 1080, "steps": steps, "ms_per_frame": dt / steps * 1e3, "rays_per_frame": int(rays),
+                "rays_per_sec": rays * steps / dt, "form": sched["form"], "frames_in_flight": args.frames_in_flight}
+    finally:
+        st.frame_width, st.frame_height = old
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,6 +164,7 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames enqueued at a time, one HIP stream each (1 = strictly one after the other; 0 = by shard size: 4 up to 4 GPUs, 6 beyond)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-1080p", action="store_true", help="skip the 1920x1080 leg that follows a 3840x2160 run")
     ap.add_argument("--pipeline", type=int, default=None, help="qd_set_pipeline: 0 = one kernel with per-lane queues, 1 = wavefront, 2 = the faster of the two, measured (library default)")
     ap.add_argument("--kd-build", type=int, default=None, help="qd_set_kd_build: 1 = device tree by SAH from the triangles, 0 = the caller's planes + refined leaves")
     ap.add_argument("--kd-refine", default=None, help="'max_leaf,step_cost' for qd_set_kd_refine (tuning; default = library default)")
@@ -119,7 +187,9 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        # host-side rendezvous only (barriers, three scalars, the 128-byte RCCL id): gloo.  The frames travel over the library's
+        # own RCCL communicator (qd_comm_*); a second RCCL communicator inside torch would only compete for its channels.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     if args.frames_in_flight == 0:
         # frames needed to keep the chip full ~ critical path of a frame (4-5 ms of dependent ray generations) / work per shard
@@ -179,8 +249,8 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / n_roof
 
     stats = fr.stats_dict()
-    rays_local = torch.tensor([stats["rays"], stats["primary_rays"], stats["shadow_rays"]], dtype=torch.float64, device=fr.dev)
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=fr.dev)
+    rays_local = torch.tensor([stats["rays"], stats["primary_rays"], stats["shadow_rays"]], dtype=torch.float64)
+    t_max = torch.tensor([elapsed], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(rays_local, op=dist.ReduceOp.SUM)
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -206,18 +276,29 @@ def main():
         n_kd = sum(1 for i in range(scene.desc.n_nodes) if scene.desc.geoms[scene.desc.nodes[i].geom].type == 5 and (scene.desc.meshes[scene.desc.geoms[scene.desc.nodes[i].geom].a].kd_root >= 0 or scene.desc.meshes[scene.desc.geoms[scene.desc.nodes[i].geom].a].flags & 4))
         launches = 3 if form == 0 else (scene.settings.max_trace_depth + 2) * (n_kd + 1)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")          # PMC sums of a separate rocprofv3 --pmc run (scripts/gpu_profile.sh)
+        ms_step = elapsed / args.steps * 1e3
+        achieved_in_flight = alg_bytes / (ms_step * 1e-3) / 1e9         # the same bytes over what a frame costs with F frames in flight
         tkey = {"synth": "synth10m_4k" if (args.mesh_n, W, H) == (2240, 3840, 2160) else None}.get(args.workload, f"{os.path.basename(args.workload).split('.')[0]}_{W}x{H}")
-        if os.path.exists(tpath) and world == 1 and tkey:
-            try:
-                traffic = json.load(open(tpath)).get(tkey, {}).get("bytes_per_frame")
-            except Exception:
-                traffic = None
+        prof, traffic_source = profiled_counters(tkey if world == 1 else None)
+        traffic = prof["bytes_per_frame"] if prof else None
+        # Which roof?  HBM is the contract's bound.  A working set that lives in L2 / MALL (counter traffic below the
+        # algorithmic bytes) is not bounded by it, and the KD walk on this chip runs into instruction issue first: both are
+        # priced beside it.  issue: a SIMD issues one wave-instruction per 4 cycles at most -> wave-instructions x 4 / (SIMDs x clock).
+        n_simd = 4 * torch.cuda.get_device_properties(local).multi_processor_count
+        other = {"l2": {"achieved": achieved, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac_lone": achieved / L2_PEAK_GBS, "frac_in_flight": achieved_in_flight / L2_PEAK_GBS,
+                        "applies": bool(traffic is not None and traffic < alg_bytes),
+                        "note": "algorithmic bytes / kernel time against the aggregate L2 bandwidth; applies when the PMC traffic is below the algorithmic bytes (the working set is served by L2 / MALL)"}}
+        if prof and prof.get("wave_insts_per_frame"):
+            wi = float(prof["wave_insts_per_frame"]["total"])
+            t_issue_ms = wi * 4.0 / (n_simd * MAX_CLOCK_HZ) * 1e3
+            other["issue"] = {"wave_insts_per_frame": wi, "by_kind": prof["wave_insts_per_frame"], "min_ms_per_frame": t_issue_ms, "simds": n_simd, "clock_hz": MAX_CLOCK_HZ,
+                              "frac_lone": t_issue_ms / kernel_ms, "frac_in_flight": t_issue_ms / ms_step,
+                              "valu_lane_util": prof.get("valu_lane_util"), "l2_hit": prof.get("l2_hit"),
+                              "note": "time the frame's wave-instructions need at one per SIMD per 4 cycles and the maximum clock, over the measured time: the fraction of the issue roof"}
         out = {
             "metric": "rays_per_sec", "value": rays_frame * args.steps / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "width": W, "height": H, "rays_per_frame": int(rays_frame),
                        "primary_rays": int(rays_local[1].item()), "shadow_rays": int(rays_local[2].item()),
@@ -225,12 +306,13 @@ def main():
                        "frames_in_flight": args.frames_in_flight, "schedule": sched,
                        "setup_s": {"host_scene": round(t_host_scene, 2), "device_scene": round(t_device_scene, 2), **{k: round(v, 2) for k, v in fr.dscene.setup_info().items()}}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "frac_lone": achieved / HBM_PEAK_GBS, "frac_in_flight": achieved_in_flight / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_source, "other_bounds": other,
                          "kernel": "trace_kernel" if form == 0 else "wf_walk_kernel + wf_shade_kernel", "kernel_ms": kernel_ms,
                          "launches_per_step": launches, "launch_avg_ms": kernel_ms / launches,
                          "note": ("one frame = 3 launches of trace_kernel (pixels, then two passes over handed-over ray tasks, usually empty)" if form == 0 else
                                   "one frame = (maxTraceDepth + 2) x (one wf_walk_kernel launch per KD-mesh node + one wf_shade_kernel launch)") +
-                                 "; kernel_ms, achieved and traffic are per frame = the sum over its launches, measured on frames that run alone (a separate untimed loop after the timed region; rocprofv3 of `bench.py --frames-in-flight 1`: TotalDurationNs / frames); the timed region overlaps frames, so ms_per_step can be below kernel_ms",
+                                 "; kernel_ms, achieved, frac (= frac_lone) and traffic are per frame = the sum over its launches, measured on frames that run alone (a separate untimed loop after the timed region; rocprofv3 of `bench.py --frames-in-flight 1`: TotalDurationNs / frames); the timed region overlaps frames, so ms_per_step can be below kernel_ms: frac_in_flight prices the same bytes on ms_per_step",
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_visit_and_test": [per_visit, per_test],
                          "kd_nodes_visited": cstats["kd_nodes_visited"], "tris_tested": cstats["tris_tested"]},
         }
@@ -239,6 +321,16 @@ def main():
             gpu_frame = fr.gather().cpu().numpy()
             fr.check()
             out["cpu_baseline"], out["parity"] = cpu_baseline(scene, gpu_frame=gpu_frame)
+    # BASELINE.json's metric also names ms/frame at 1080p: the same scene, same form choice, same frames in flight at 1920x1080,
+    # after the timed region (never part of `value`); every rank takes part (the frames are gathered)
+    small = None
+    if (W, H) == (3840, 2160) and not args.no_1080p:
+        small = leg_1080p(args, scene, fr, rank, world, local, barrier)
+    if rank == 0:
+        if small:
+            out["config"]["ms_per_frame_1080p"] = small["ms_per_frame"]
+            out["config"]["rays_per_sec_1080p"] = small["rays_per_sec"]
+            out["config"]["leg_1080p"] = small
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

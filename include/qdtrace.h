@@ -412,17 +412,18 @@ int qd_set_counting(int on);
 /* Replaces: nothing in the reference (its Raytrace recursion has one form).  Selects how a frame is scheduled on the GPU:
  * 0 = one persistent kernel, every lane with its own LIFO queue of ray tasks (memory bounded by queue depth x lanes);
  * 1 = wavefront pipeline: generations of rays in HBM queues, a KD walk kernel per mesh node that refills idle lanes inside
- *     its loop and a full-width shading kernel per generation (queues sized pixels x (tasks per hit + 1) within 16 GB per
- *     working set, at least 4 and, beyond the budget, at most 8 per pixel; a
- *     generation that outgrows them raises the scene's error flag: the synchronous entry points then render the call again
- *     in form 0, the asynchronous ones report it through qd_scene_check and keep the scene on form 0 afterwards);
+ *     its loop and a full-width shading kernel per generation.  Queues hold max(4, tasks per hit + 1) entries per pixel
+ *     within 16 GB per working set; a frame that asks for more (25 glossy samples at 4K) is rendered in bands of whole
+ *     8 x 8 units, one after the other on the stream.  No call fails over the queues: a generation that still outgrows
+ *     them (glass that keeps doubling) sets a device word, and the launch that follows every band on the stream -- the
+ *     band once more in form 0, which returns at once when the word is clear -- renders that band again in place; the
+ *     scene then stays on form 0 (qd_scene_wavefront_info tells).  The frame is complete and correct either way;
  * 2 = (default) the faster of the two for the scene at hand: each form is timed with HIP events on frames of the scene that
  *     ran alone on the GPU (enqueued when the scene's earlier work had finished, finished before the next launch; read
  *     without waiting), a form's first such frame is dropped, the faster form renders, and a caller that waits for its
  *     frames sends every 64th to the other form.  A caller that keeps several frames in flight renders a few frames one
  *     at a time first (FrameRenderer.settle(): 6); frames that overlap are never timed.  Until there are figures the
- *     scene renders in form 1, or in form 0 if its device tree has more than 4 M nodes or its shaders can queue more
- *     rays per pixel than the queues of form 1 are granted.
+ *     scene renders in form 1, or in form 0 if its device tree has more than 4 M nodes.
  *     Which one wins depends on the frame: form 1 where rays have very different fates (the reference's kdtree_test: 2x),
  *     form 0 where all pixels carry similar work (the 10 M triangle terrain: 1.3x).
  * Same arithmetic in both forms, same results up to the order of float additions.  Applies to calls made after it. */
@@ -431,6 +432,13 @@ int qd_set_pipeline(int pipeline);
  * pixel slot of each form in nanoseconds (0 = not measured yet); also reads the latest frame's events if that frame ran
  * alone and has finished.  Any pointer may be NULL. */
 int qd_scene_schedule_info(const qd_scene* scene, int* last_form, double* ns_per_pixel_form0, double* ns_per_pixel_form1);
+
+/* Replaces: nothing in the reference.  Memory the ray queues of form 1 may take per working set (default 16 GB; 0 = default):
+ * a frame beyond the budget is rendered in bands.  max_entries, for tests (0 = off): a cap on the entries of a queue that the
+ * band sizes do not take into account, so that bands overflow and the in-stream fallback runs.  qd_scene_wavefront_info: the bands a width x height frame of this scene takes, and whether a
+ * band of the scene ever outgrew its queues (it was rendered again in form 0 on the spot, and the scene stays on form 0). */
+int qd_set_wavefront_budget(uint64_t queue_bytes, uint32_t max_entries);
+int qd_scene_wavefront_info(const qd_scene* scene, int width, int height, uint32_t* bands, int* overflowed);
 
 /* Replaces: the leaf criterion of Mesh::BuildKD (src/mesh.cpp:218, TRIANGLES_PER_LEAF = 20 in
  * src/constants.h:14) for the DEVICE copy of the tree only.  qd_scene_create keeps the caller's
@@ -463,8 +471,9 @@ int qd_scene_kd_info(const qd_scene* scene, uint64_t* nodes, uint64_t* leaf_refs
  * scene + gathering the leaf vertices on the device.  Replaces: the "KD-tree built in %.2lfs" report of src/mesh.cpp:209. */
 int qd_scene_setup_info(const qd_scene* scene, double* kd_build_seconds, double* upload_seconds);
 
-/* Replaces: nothing in the reference (its render loop cannot fail).  Returns <0 if an asynchronous
- * launch on this scene overflowed its ray queue since the last check (synchronises the device). */
+/* Replaces: nothing in the reference (its render loop cannot fail).  Returns <0 if an asynchronous launch on this scene raised
+ * a device error word since the last check (the per-lane ray queue of form 0 overflowed -- its depth is derived from the shader
+ * graph, so this says the description lied about it; synchronises the device).  The queues of form 1 never raise it. */
 int qd_scene_check(qd_scene* scene);
 
 void qd_scene_destroy(qd_scene* scene);

@@ -68,6 +68,8 @@ struct Params {
     int x0, y0, rw, rh;           // rectangle
     int tile, tiles_x, phase, stride;
     uint32_t n_units;             // 8x8 pixel units to render
+    uint32_t unit0;               // first unit of this launch (a frame rendered in bands: wavefront form, see launch_wavefront)
+    const uint32_t* cond;         // not null: the launch does nothing unless *cond != 0 (the in-stream fallback of a wavefront band)
     uint32_t units_x;             // rectangle mode: units per row
     uint32_t* queue_ctr;          // 8 work-queue counters, kCtlStride words apart (zeroed before launch)
     uint64_t* stack;              // ray task workspace
@@ -88,6 +90,10 @@ struct Params {
     uint64_t* out_list; uint32_t* out_count; size_t list_cap;   // eight regions of list_cap / 8 tasks with a count each
     // wavefront pipeline (wavefront.h): two ray queues (generations alternate), hit records, control words, deep KD stack levels
     uint64_t* wf_ray[2]; uint64_t* wf_res; uint32_t* wf_ctl; uint2* wf_deep; uint32_t wf_cap;
+    uint32_t wf_limit;                   // entries of a queue that appends may fill (= wf_cap; smaller only under qd_set_wavefront_budget's test switch)
+    uint32_t* wf_over;                   // set by an append that finds its queue full (the band is then rendered again, see wf_band_end_kernel)
+    unsigned long long* user_stats;      // wavefront form: the caller's counters; `stats` is then the band's own block
+    uint32_t* host_flag;                 // pinned host word: "a wavefront band of this scene overflowed"
 };
 
 struct Task {
@@ -522,6 +528,7 @@ QD_DEV PixelSlot map_pixel(const Params& P, uint32_t unit, uint32_t p) {
 constexpr int kFlatWavesPerEU = 3, kFlatLdsStack = 12;
 template <bool STATS, int GEOM, bool RICH, bool FLAT = false>
 __global__ __launch_bounds__(64, FLAT ? kFlatWavesPerEU : QD_WAVES_PER_EU) void trace_kernel(const DScene S, const Params P) {
+    if (P.cond && __hip_atomic_load(P.cond, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;      // a fallback launch with nothing to fall back for
     const uint32_t lane = threadIdx.x;
     const size_t gl = (size_t)blockIdx.x * 64 + lane;
     LaneQueue q;
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(64, FLAT ? kFlatWavesPerEU : QD_WAVES_PER_EU) void 
                 q.sp = 1;
             } else if (q.sp == 0 && rank < got) {
                 const uint32_t slot = first + rank;
-                const PixelSlot px = map_pixel(P, slot / kUnitPx, slot % kUnitPx);
+                const PixelSlot px = map_pixel(P, P.unit0 + slot / kUnitPx, slot % kUnitPx);
                 if (px.valid) {
                     // Camera::GetScreenRay, src/camera.cpp:26-41 (integer pixel coordinates, no +0.5)
                     const DV TL = ld3(P.cam.top_left), TR = ld3(P.cam.top_right), BL = ld3(P.cam.bottom_left), pos = ld3(P.cam.position);
@@ -932,6 +939,8 @@ bool g_counting = false;
 int g_pipeline = 2;           // qd_set_pipeline: 0 = one persistent kernel with per-lane LIFO queues, 1 = wavefront pipeline (wavefront.h), 2 = the faster of the two, measured per scene
 int g_refine_leaf = 2;        // qd_set_kd_refine
 double g_refine_cost = 0.6;
+uint64_t g_wf_budget = 16ull << 30;   // qd_set_wavefront_budget: bytes of ray queues per working set (wavefront form); for tests, a cap on the
+uint32_t g_wf_max_entries = 0;        // entries of a queue that the band sizes do NOT take into account (0 = none): bands then overflow
 int g_kd_build = 1;           // qd_set_kd_build: 0 = the caller's planes, leaves refined; 1 = whole tree by the surface-area heuristic, built on the device (kdbuild.h); 2 = the same by host threads (kdrefine.h)
 
 int set_err(const std::string& m) { g_err = m; return -1; }
@@ -1040,8 +1049,10 @@ struct qd_scene {
     FormSample sample;                   // the latest frame, if it started alone
     bool serial_caller = false;          // the latest sample was accepted: the caller waits for its frames
     uint64_t form_frames = 0;
-    bool wavefront_overflowed = false;
-    int last_form = 0;                   // form of the most recent launch (the synchronous entry points retry an overflowed wavefront frame in the other)
+    bool wavefront_overflowed = false;   // a band of the wavefront form outgrew its queues once: the scene stays on the one-kernel form
+    uint32_t* host_flag = nullptr;       // pinned host word the device sets when that happens (read without waiting), and its device address
+    uint32_t* host_flag_dev = nullptr;
+    int last_form = 0;                   // form of the most recent launch (qd_scene_schedule_info)
     uint64_t kd_nodes = 0, kd_refs = 0, kd_leaves = 0, kd_max_leaf = 0;   // device tree after refinement
     double t_kd_build = 0., t_upload = 0.;   // seconds of qd_scene_create spent building the device KD tree / uploading and gathering
 };
@@ -1125,34 +1136,41 @@ constexpr uint32_t kGrace = QD_GRACE;
 
 constexpr uint32_t kWfMaxGens = 67;          // generations a frame may have: maxTraceDepth + 2
 
-// Entries of a wavefront ray queue for a launch over n_slots pixel slots (see reserve_wavefront).
-uint64_t wavefront_queue_cap(const qd_scene* s, uint64_t n_slots) {
+// Ray queues of the wavefront form for a launch over n_slots pixel slots: entries per queue (`cap`) and pixel slots per
+// band.  A generation holds at most (rays of the one before) x (tasks queued per hit); generation 1 is bounded by
+// pixels x spawn0, later ones shrink in every scene measured (rays leave the scene faster than glass doubles them), so a band
+// is granted max(4, spawn0 + 1) entries per pixel slot.  Within 16 GB per working set: a frame that asks for more (a 25-sample
+// glossy floor at 4K: 28 entries per pixel, 41 GB) is rendered in BANDS of whole 8 x 8 units, one after the other on the
+// stream, each with its own loop over the generations and the same queues.
+struct WfPlan { uint64_t cap; uint64_t band_slots; };
+WfPlan wavefront_plan(const qd_scene* s, uint64_t n_slots) {
     const size_t n_kd = std::max<size_t>(1, s->kd_node_list.size());
     const uint64_t entry_bytes = 2ull * kEntryWords * 8 + (uint64_t)kWfResWords * 8 * n_kd;
-    const uint64_t per_px_max = std::max<uint64_t>(8, (16ull << 30) / std::max<uint64_t>(1, n_slots * entry_bytes));
-    uint64_t cap64 = n_slots * std::min<uint64_t>(per_px_max, std::max<uint64_t>(4, (uint64_t)s->spawn0 + 1));
+    const uint64_t budget = std::max<uint64_t>(kUnitPx * 4, std::min<uint64_t>(g_wf_budget / entry_bytes, (1ull << 31) - 1));
+    const uint64_t demand = std::max<uint64_t>(4, (uint64_t)s->spawn0 + 1);
+    uint64_t want = n_slots * demand;
     // small launches (a bucket, a rectangle that lies on glass) get up to 32 entries per pixel while that stays below 8 M entries
-    cap64 = std::max<uint64_t>(cap64, std::min<uint64_t>(n_slots * 32, 8u << 20));
-    return std::max<uint64_t>(cap64, 1u << 16);
+    want = std::max<uint64_t>(want, std::min<uint64_t>(n_slots * 32, 8u << 20));
+    want = std::max<uint64_t>(want, 1u << 16);
+    WfPlan p;
+    p.cap = std::min(want, budget);
+    p.band_slots = p.cap >= n_slots * demand ? n_slots : std::max<uint64_t>(kUnitPx, p.cap / demand / kUnitPx * kUnitPx);
+    return p;
 }
+
+// words behind the per-generation control words of a working set: the overflow word (a cache line), then the band's counters
+constexpr size_t kWfTail = (size_t)(kWfMaxGens + 1) * kWfGenWords;
+constexpr size_t kWfTailWords = kCtlStride + 24 * 2;
 
 // The wavefront form of a frame (wavefront.h): walk(0) shade(0) walk(1) ... walk(D + 1) shade(D + 1) on the stream.
 // ... its buffers first (apart from the launches, so that the adaptive choice does not time an allocation):
 int reserve_wavefront(qd_scene* s, WorkSet* w, const Params& P, uint32_t max_depth) {
     if (max_depth + 3 > kWfMaxGens) return set_err("maxTraceDepth too large for the wavefront pipeline");
-    const uint64_t n_slots = (uint64_t)P.n_units * kUnitPx;
-    // queue capacity: a generation holds at most (rays of the one before) x (tasks queued per hit); generation 1 is bounded
-    // by pixels x spawn0, later ones shrink in every scene measured (rays leave the scene faster than glass doubles them):
-    // pixels x max(4, spawn0 + 1).  An overflow raises the scene's error flag, it never writes out of bounds: the synchronous
-    // entry points then render the call again in the one-kernel form (whose queues are bounded by construction), the
-    // asynchronous ones report it through qd_scene_check.
-    // ... within a memory budget of 16 GB per working set, and 8 per pixel whatever they cost: a 25-sample glossy scene asks for
-    // 28 entries per pixel (12 GB at 1920x1080, where the form is up to 2x faster for such a scene; 48 GB at 4K, where it
-    // is not); a scene that really fills more than it got in one generation overflows once and stays on the one-kernel form.
     const size_t n_kd = std::max<size_t>(1, s->kd_node_list.size());
-    const uint64_t cap64 = wavefront_queue_cap(s, n_slots);
-    if (cap64 >= (1ull << 31)) return set_err("frame too large for the wavefront ray queues (split it into rectangles)");
-    if (!w->wf_ctl) HIP_TRY(hipMalloc((void**)&w->wf_ctl, (size_t)(kWfMaxGens + 1) * kWfGenWords * sizeof(uint32_t)));
+    const uint64_t cap64 = wavefront_plan(s, (uint64_t)P.n_units * kUnitPx).cap;
+    // (no clearing here: a memset on the null stream is not ordered with the caller's stream and could land in the middle of the
+    // frame; every band clears the words it uses on its own stream)
+    if (!w->wf_ctl) HIP_TRY(hipMalloc((void**)&w->wf_ctl, (kWfTail + kWfTailWords) * sizeof(uint32_t)));
     if (!w->wf_deep) HIP_TRY(hipMalloc((void**)&w->wf_deep, (size_t)(kKdStack - kLdsStack) * s->n_lanes * sizeof(uint2)));
     if (cap64 > w->wf_cap) {
         for (void** p : {(void**)&w->wf_ray[0], (void**)&w->wf_ray[1], (void**)&w->wf_res}) if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -1164,13 +1182,26 @@ int reserve_wavefront(qd_scene* s, WorkSet* w, const Params& P, uint32_t max_dep
     return 0;
 }
 
+int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hipStream_t stream, bool fallback = false);
+
+// The queues cannot be outgrown unnoticed -- and not at the price of a frame either.  An append that finds its queue full
+// sets the working set's overflow word and writes nothing.  Behind every band, on the stream: wf_band_end_kernel (no overflow:
+// the band's counters go to the caller's; overflow: the band's pixels are zeroed) and ONE launch of the one-kernel form on
+// the same band that returns at once unless the word is set (its per-lane queues are bounded by construction).  So the frame
+// is complete and correct either way, nothing comes back to the host and no call fails; a band that overflowed cost its time
+// twice, and the pinned host word keeps the scene on the one-kernel form from the next launch on.
 int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hipStream_t stream) {
     if (reserve_wavefront(s, w, P, max_depth)) return -1;          // (a no-op when launch() has reserved already)
     const uint64_t n_slots = (uint64_t)P.n_units * kUnitPx;
+    const WfPlan plan = wavefront_plan(s, n_slots);
     P.wf_ray[0] = w->wf_ray[0]; P.wf_ray[1] = w->wf_ray[1]; P.wf_res = w->wf_res; P.wf_ctl = w->wf_ctl; P.wf_deep = w->wf_deep;
     P.wf_cap = (uint32_t)w->wf_cap;
+    P.wf_limit = g_wf_max_entries ? std::min<uint32_t>(P.wf_cap, std::max<uint32_t>(g_wf_max_entries, 64u)) : P.wf_cap;
     P.error_flag = s->error_flag + (w - s->sets);
-    HIP_TRY(hipMemsetAsync(w->wf_ctl, 0, (size_t)(max_depth + 3) * kWfGenWords * sizeof(uint32_t), stream));
+    P.wf_over = w->wf_ctl + kWfTail;
+    P.host_flag = s->host_flag_dev;
+    unsigned long long* const band_stats = (unsigned long long*)(w->wf_ctl + kWfTail + kCtlStride);
+    unsigned long long* const user_stats = P.stats;
     HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));
     using ShadeK = void (*)(const DScene, const Params, int);
     // call-free copies by scene content (see wf_nodes); a scene that needs a call -- a mesh too small for a tree, a Layered
@@ -1190,21 +1221,36 @@ int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hip
     const ShadeK sk = g_counting ? wf_shade_kernel<true, kGeomAll, true, true> : needs_calls ? wf_shade_kernel<false, kGeomAll, true, true>
                                  : (s->rich ? shade_rich : shade_plain)[s->geom_mask & 7];
     const uint32_t max_blocks = s->n_lanes / 64;
-    const uint32_t grid0 = (uint32_t)std::min<uint64_t>(max_blocks, std::max<uint64_t>(1, (n_slots + 63) / 64));
-    for (uint32_t g = 0; g <= max_depth + 1; ++g) {
-        for (size_t k = 0; k < s->kd_node_list.size(); ++k) {
-            if (g_counting) hipLaunchKernelGGL(wf_walk_kernel<true>, dim3(grid0), dim3(64), 0, stream, s->d, P, (int)g, s->kd_node_list[k], (int)k);
-            else hipLaunchKernelGGL(wf_walk_kernel<false>, dim3(grid0), dim3(64), 0, stream, s->d, P, (int)g, s->kd_node_list[k], (int)k);
+    const uint32_t all_units = P.n_units, first_unit = P.unit0;
+    const uint32_t band_units = (uint32_t)(plan.band_slots / kUnitPx);
+    for (uint32_t u = 0; u < all_units; u += band_units) {
+        P.unit0 = first_unit + u;
+        P.n_units = std::min(band_units, all_units - u);
+        const uint64_t band_slots = (uint64_t)P.n_units * kUnitPx;
+        const uint32_t grid0 = (uint32_t)std::min<uint64_t>(max_blocks, std::max<uint64_t>(1, (band_slots + 63) / 64));
+        HIP_TRY(hipMemsetAsync(w->wf_ctl, 0, (size_t)(max_depth + 3) * kWfGenWords * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(w->wf_ctl + kWfTail, 0, kWfTailWords * sizeof(uint32_t), stream));
+        P.stats = band_stats; P.user_stats = user_stats; P.cond = nullptr;
+        for (uint32_t g = 0; g <= max_depth + 1; ++g) {
+            for (size_t k = 0; k < s->kd_node_list.size(); ++k) {
+                if (g_counting) hipLaunchKernelGGL(wf_walk_kernel<true>, dim3(grid0), dim3(64), 0, stream, s->d, P, (int)g, s->kd_node_list[k], (int)k);
+                else hipLaunchKernelGGL(wf_walk_kernel<false>, dim3(grid0), dim3(64), 0, stream, s->d, P, (int)g, s->kd_node_list[k], (int)k);
+                HIP_TRY(hipGetLastError());
+            }
+            hipLaunchKernelGGL(sk, dim3(grid0), dim3(64), 0, stream, s->d, P, (int)g);
             HIP_TRY(hipGetLastError());
         }
-        hipLaunchKernelGGL(sk, dim3(grid0), dim3(64), 0, stream, s->d, P, (int)g);
+        hipLaunchKernelGGL(wf_band_end_kernel, dim3((unsigned)((band_slots + 63) / 64)), dim3(64), 0, stream, P);
         HIP_TRY(hipGetLastError());
+        P.stats = user_stats; P.cond = P.wf_over;                      // the fallback: does nothing unless the band overflowed
+        if (launch_one_kernel(s, w, P, max_depth, stream, true)) return -1;
     }
+    P.unit0 = first_unit; P.n_units = all_units; P.stats = user_stats; P.cond = nullptr;
     HIP_TRY(hipEventRecord(w->idle, stream));
     return 0;
 }
 
-int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hipStream_t stream);
+
 
 // Adaptive choice (qd_set_pipeline 2, the default): which form is faster depends on the frame -- the wavefront form wins
 // where rays have very different fates (a glass object in front of a backdrop: the reference's kdtree_test, 2x) and,
@@ -1235,9 +1281,8 @@ void read_sample(qd_scene* s, bool at_launch) {
 // 2.6x; scripts/gpu_forms.py) and loses where a frame is launch-bound (hw9/axe_test, 0.5 against 1.0 ms) or the tree is
 // deep (the 10 M triangle terrain, 46 M records: 0.65x).  So: wavefront, unless the tree is large or the shader graph asks
 // for more queue entries per pixel than reserve_wavefront grants for the frame.
-int prior_form(const qd_scene* s, uint64_t n_slots) {
+int prior_form(const qd_scene* s, uint64_t) {
     if (s->kd_nodes > (4u << 20)) return 0;
-    if (wavefront_queue_cap(s, n_slots) < n_slots * ((uint64_t)s->spawn0 + 1)) return 0;     // generation 1 might not fit
     return 1;
 }
 
@@ -1258,6 +1303,7 @@ int launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream) {
     WorkSet* w = nullptr;
     if (acquire_set(s, stream, max_depth, &w)) return -1;
     read_sample(s, true);
+    if (s->host_flag && *(volatile uint32_t*)s->host_flag) s->wavefront_overflowed = true;     // a band outgrew its queues (and was rendered again in place)
     const int form = choose_form(s, (uint64_t)P.n_units * kUnitPx);
     bool alone = g_pipeline == 2;                         // does this frame start on a drained GPU (as far as this scene goes)?
     for (auto& c : s->sets) if (alone && c.t1 && hipEventQuery(c.t1) != hipSuccess) alone = false;
@@ -1279,23 +1325,25 @@ int launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream) {
     return 0;
 }
 
-int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hipStream_t stream) {
+// fallback: the launch behind a wavefront band (P.cond set): one pass that runs to the end, the frame buffer is left alone
+int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hipStream_t stream, bool fallback) {
     P.stack = w->stack; P.stack_cap = w->stack_cap; P.n_lanes = s->n_lanes;
     P.error_flag = s->error_flag + (w - s->sets);
     P.list_cap = w->list_cap;
-    HIP_TRY(hipMemsetAsync(w->queue_ctr, 0, (size_t)kPasses * kPassWords * sizeof(uint32_t), stream));
-    HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));       // the kernel adds colours into it
+    HIP_TRY(hipMemsetAsync(w->queue_ctr, 0, (size_t)(fallback ? 1 : kPasses) * kPassWords * sizeof(uint32_t), stream));
+    if (!fallback) HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));       // the kernel adds colours into it
     // the copy for meshes + planes without texture code runs 3 waves per SIMD (FLAT, see trace_kernel): fewer persistent waves
     const bool flat = !g_counting && (s->geom_mask & 15) == 0 && !s->nested_layered;
     const uint32_t max_blocks = flat ? s->n_lanes / 64 / (uint32_t)QD_WAVES_PER_EU * (uint32_t)kFlatWavesPerEU : s->n_lanes / 64;
-    for (int pass = 0; pass < kPasses; ++pass) {
+    const int n_passes = fallback ? 1 : kPasses;
+    for (int pass = 0; pass < n_passes; ++pass) {
         uint32_t* ctl = w->queue_ctr + (size_t)pass * kPassWords;
         P.queue_ctr = ctl; P.out_count = ctl + 8 * kCtlStride; P.pass_done = ctl + 16 * kCtlStride;
         P.source = pass == 0 ? 0 : 1;
         P.in_count = pass == 0 ? nullptr : ctl - kPassWords + 8 * kCtlStride;
         P.in_list = pass == 0 ? nullptr : w->lists[(pass - 1) & 1];
         P.out_list = w->lists[pass & 1];
-        P.grace = pass == kPasses - 1 ? 0xffffffffu : kGrace;
+        P.grace = pass == n_passes - 1 ? 0xffffffffu : kGrace;
         // later passes usually find an empty list; a launch costs ~45 ns per wave (scratch set-up), so they start fewer waves
         const uint32_t grid = pass == 0 ? (P.n_units < max_blocks ? (P.n_units ? P.n_units : 1) : max_blocks) : (max_blocks + kLaterPassDiv - 1) / kLaterPassDiv;
         using Kernel = void (*)(const DScene, const Params);
@@ -1317,7 +1365,7 @@ int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hi
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, stream, s->d, P);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(w->idle, stream));
+    if (!fallback) HIP_TRY(hipEventRecord(w->idle, stream));
     return 0;
 }
 
@@ -1334,9 +1382,10 @@ int stage(qd_scene* s, int which, size_t bytes, void** out) {
     return 0;
 }
 
-// What a synchronous entry point does around its launches: counters and error flag cleared, events around the launches,
-// wait, error flag read; a wavefront frame whose queues overflowed is rendered again in the one-kernel form (whose queues
-// are bounded by construction).  `begin_only` stops after the enqueue (qd_frame_begin); finish_launch does the rest.
+// What a synchronous entry point does around its launches: counters cleared, events around the launches, wait, the working
+// set's error word read (and cleared if raised; it is never cleared ahead of a launch, so a qd_render between qd_frame_begin
+// and the frame's first read cannot wipe the frame's error).  `begin_only` stops after the enqueue (qd_frame_begin);
+// finish_launch does the rest.
 int finish_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream, float* ms, bool frame_events);
 int timed_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream, float* ms, bool begin_only = false, bool frame_events = false) {
     Staging& g = s->stg;
@@ -1348,13 +1397,12 @@ int timed_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream,
     HIP_TRY(hipMemsetAsync(P.stats, 0, 24 * sizeof(unsigned long long), stream));             // the call's own counters (P.stats)
     HIP_TRY(hipMemsetAsync(P.stats + 16, 0xff, sizeof(unsigned long long), stream));
     HIP_TRY(hipMemsetAsync(P.stats + 19, 0xff, sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(s->error_flag + (w - s->sets), 0, sizeof(int), stream));
     HIP_TRY(hipEventRecord(e0, stream));
     if (launch(s, P, max_depth, stream)) return -1;
     HIP_TRY(hipEventRecord(e1, stream));
     return begin_only ? 0 : finish_launch(s, P, max_depth, stream, ms, frame_events);
 }
-int finish_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream, float* ms, bool frame_events) {
+int finish_launch(qd_scene* s, Params&, uint32_t, hipStream_t stream, float* ms, bool frame_events) {
     Staging& g = s->stg;
     HIP_TRY(hipEventSynchronize(frame_events ? g.f1 : g.e1));
     if (ms) HIP_TRY(hipEventElapsedTime(ms, frame_events ? g.f0 : g.e0, frame_events ? g.f1 : g.e1));
@@ -1364,14 +1412,6 @@ int finish_launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream
     int* flag = s->error_flag + (w - s->sets);
     int err_flag = 0;
     HIP_TRY(hipMemcpy(&err_flag, flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (err_flag == 1 && w->last_form == 1) {
-        s->wavefront_overflowed = true;
-        const int saved_pipeline = g_pipeline;
-        g_pipeline = 0;
-        const int rc = timed_launch(s, P, max_depth, stream, ms, false, frame_events);
-        g_pipeline = saved_pipeline;
-        return rc;
-    }
     if (err_flag) {
         (void)hipMemset(flag, 0, sizeof(int));
         return set_err("ray queue overflow on device");
@@ -1714,6 +1754,9 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     if (!rc && hipMalloc((void**)&s->stats, (24 + 6 * 4096) * sizeof(unsigned long long)) != hipSuccess) rc = set_err("hipMalloc(stats) failed");
     if (!rc && hipMalloc((void**)&s->error_flag, kErrFlags * sizeof(int)) != hipSuccess) rc = set_err("hipMalloc(error flags) failed");
     if (!rc && hipMemset(s->error_flag, 0, kErrFlags * sizeof(int)) != hipSuccess) rc = set_err("hipMemset failed");
+    if (!rc && (hipHostMalloc((void**)&s->host_flag, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+                hipHostGetDevicePointer((void**)&s->host_flag_dev, s->host_flag, 0) != hipSuccess)) rc = set_err("hipHostMalloc(overflow word) failed");
+    if (!rc) *s->host_flag = 0u;
     if (!rc) {                                   // working set of the default stream, so that a first render allocates nothing
         WorkSet* w = nullptr;
         rc = acquire_set(s, nullptr, desc->settings.max_trace_depth, &w);
@@ -1736,6 +1779,7 @@ extern "C" void qd_scene_destroy(qd_scene* s) {
     if (s->stg.f1) (void)hipEventDestroy(s->stg.f1);
     if (s->stats) (void)hipFree(s->stats);
     if (s->error_flag) (void)hipFree(s->error_flag);
+    if (s->host_flag) (void)hipHostFree(s->host_flag);
     delete s;
 }
 
@@ -1963,14 +2007,12 @@ int aa_end(qd_scene* s, const qd_settings* st, const float* taps_dev, float* rgb
         TRY2(hipMemcpy(changed, d_changed, sizeof changed, hipMemcpyDeviceToHost));
         for (int k = 0; k < kAaBatch; ++k) if (!changed[k]) settled = true;
     }
-    int flags[kErrFlags];                                  // the rule's own word, and those of the sets that traced the taps
-    TRY2(hipMemcpy(flags, s->error_flag, sizeof flags, hipMemcpyDeviceToHost));
-    bool overflow = false;
-    for (int i = 0; i < kMaxWorkSets; ++i) overflow |= flags[i] != 0;
-    if (flags[kErrAa] || overflow) {
-        (void)hipMemset(s->error_flag, 0, sizeof flags);
+    int rule_flag = 0;                                     // the rule's own word (the sets that traced the taps report through qd_scene_check / their own calls)
+    TRY2(hipMemcpy(&rule_flag, s->error_flag + kErrAa, sizeof rule_flag, hipMemcpyDeviceToHost));
+    if (rule_flag) {
+        (void)hipMemset(s->error_flag + kErrAa, 0, sizeof rule_flag);
         cleanup();
-        return set_err(flags[kErrAa] ? "qd_antialias: marked pixel outside the traced set" : "qd_antialias: ray queue overflow on device");
+        return set_err("qd_antialias: marked pixel outside the traced set");
     }
     TRY2(hipMemcpy(rgb_dev, cur, npx * 3 * sizeof(float), hipMemcpyDeviceToDevice));
     cleanup();
@@ -2007,27 +2049,14 @@ int antialias_impl(qd_scene* s, const qd_camera* cam, const qd_settings* st, flo
         WorkSet* w0 = nullptr;
         if (acquire_set(s, nullptr, st->max_trace_depth, &w0)) { cleanup(); return -1; }
         int* const flag = s->error_flag + (w0 - s->sets);          // the error word of the set these launches use
-        TRY2(hipMemsetAsync(flag, 0, sizeof(int), nullptr));
         TRY2(hipEventRecord(g.e0, nullptr));
         if (aa_trace(s, cam, st, 0, n_list, d_taps, s->stats, nullptr)) { cleanup(); return -1; }
         TRY2(hipEventRecord(g.e1, nullptr));
         TRY2(hipEventSynchronize(g.e1));
         TRY2(hipEventElapsedTime(&ms, g.e0, g.e1));
-        if (w0->last_form == 1) {               // taps that outgrew the wavefront queues: once more in the one-kernel form
-            int err_flag = 0;
-            TRY2(hipMemcpy(&err_flag, flag, sizeof(int), hipMemcpyDeviceToHost));
-            if (err_flag == 1) {
-                s->wavefront_overflowed = true;
-                const int saved_pipeline = g_pipeline;
-                TRY2(hipMemsetAsync(s->stats, 0, 16 * sizeof(unsigned long long), nullptr));
-                TRY2(hipMemsetAsync(flag, 0, sizeof(int), nullptr));
-                g_pipeline = 0;
-                const int rc2 = aa_trace(s, cam, st, 0, n_list, d_taps, s->stats, nullptr);
-                g_pipeline = saved_pipeline;
-                if (rc2) { cleanup(); return -1; }
-                TRY2(hipDeviceSynchronize());
-            }
-        }
+        int err_flag = 0;
+        TRY2(hipMemcpy(&err_flag, flag, sizeof(int), hipMemcpyDeviceToHost));
+        if (err_flag) { (void)hipMemset(flag, 0, sizeof(int)); cleanup(); return set_err("qd_antialias: ray queue overflow on device"); }
     }
     if (aa_end(s, st, d_taps, frame)) { cleanup(); return -1; }
     if (!rgb_dev) TRY2(hipMemcpy2D(rgb, pitch * sizeof(float), frame, (size_t)W * 3 * sizeof(float), (size_t)W * 3 * sizeof(float), H, hipMemcpyDeviceToHost));
@@ -2190,16 +2219,31 @@ extern "C" int qd_scene_check(qd_scene* s) {
     std::lock_guard<std::mutex> lock(s->mu);
     int f[kErrFlags];
     HIP_TRY(hipMemcpy(f, s->error_flag, sizeof f, hipMemcpyDeviceToHost));
-    bool any = false, wavefront = false;
-    for (int i = 0; i < kErrFlags; ++i) if (f[i]) { any = true; if (i < kMaxWorkSets && s->sets[i].last_form == 1) wavefront = true; }
+    bool any = false;
+    for (int i = 0; i < kErrFlags; ++i) any |= f[i] != 0;
+    if (s->host_flag && *(volatile uint32_t*)s->host_flag) s->wavefront_overflowed = true;
     if (any) {
         (void)hipMemset(s->error_flag, 0, sizeof f);
-        if (wavefront) {               // a generation outgrew the wavefront queues: this scene stays on the one-kernel form from here on
-            s->wavefront_overflowed = true;
-            return set_err("ray queue overflow on device (wavefront form; the scene's next frames use the one-kernel form, whose queues cannot overflow)");
-        }
         return set_err("ray queue overflow on device");
     }
+    return 0;
+}
+
+extern "C" int qd_set_wavefront_budget(uint64_t queue_bytes, uint32_t max_entries) {
+    g_wf_budget = queue_bytes ? queue_bytes : (16ull << 30);
+    g_wf_max_entries = max_entries;
+    return 0;
+}
+
+extern "C" int qd_scene_wavefront_info(const qd_scene* cs, int width, int height, uint32_t* bands, int* overflowed) {
+    if (!cs || width <= 0 || height <= 0) return set_err("qd_scene_wavefront_info: bad argument");
+    qd_scene* s = const_cast<qd_scene*>(cs);
+    std::lock_guard<std::mutex> lock(s->mu);
+    const uint64_t n_slots = (uint64_t)((width + kUnitSide - 1) / kUnitSide) * (uint64_t)((height + kUnitSide - 1) / kUnitSide) * kUnitPx;
+    const WfPlan plan = wavefront_plan(s, n_slots);
+    if (bands) *bands = (uint32_t)((n_slots + plan.band_slots - 1) / plan.band_slots);
+    if (s->host_flag && *(volatile uint32_t*)s->host_flag) s->wavefront_overflowed = true;
+    if (overflowed) *overflowed = s->wavefront_overflowed ? 1 : 0;
     return 0;
 }
 

@@ -42,7 +42,7 @@ constexpr uint32_t kWfBlock = 128;               // indices a wave reserves with
 
 // Appends tasks to the next generation's queue: one atomic per call site and wave (the lanes that reach the call together).
 struct WfAppender {
-    uint64_t* base; size_t cap; uint32_t* count; int* err; uint32_t max_depth; uint32_t n_killed;
+    uint64_t* base; size_t cap; size_t limit; uint32_t* count; uint32_t* over; uint32_t max_depth; uint32_t n_killed;
     unsigned long long lanes_below;
     QD_DEV void push(const Task& t) {
         if (!(t.flags_depth & kFlagShadow) && (t.flags_depth & kDepthMask) > max_depth) { ++n_killed; return; }   // src/main.cpp:20-21
@@ -52,7 +52,7 @@ struct WfAppender {
         if (rank == 0) first = atomicAdd(count, (uint32_t)__popcll(m));
         first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
         const size_t i = (size_t)first + rank;
-        if (i >= cap) { *err = 1; return; }
+        if (i >= limit) { *over = 1u; return; }          // the band is rendered again in the one-kernel form (wf_band_end_kernel)
         uint64_t* p = base + i;
         p[0 * cap] = __double_as_longlong(t.o.x); p[1 * cap] = __double_as_longlong(t.o.y); p[2 * cap] = __double_as_longlong(t.o.z);
         p[3 * cap] = __double_as_longlong(t.d.x); p[4 * cap] = __double_as_longlong(t.d.y); p[5 * cap] = __double_as_longlong(t.d.z);
@@ -65,7 +65,7 @@ struct WfAppender {
 
 // The primary ray of pixel slot `slot` (Camera::GetScreenRay, src/camera.cpp:26-41); false for a slot outside the frame.
 QD_DEV bool wf_primary(const Params& P, uint32_t slot, Task& t) {
-    const PixelSlot px = map_pixel(P, slot / kUnitPx, slot % kUnitPx);
+    const PixelSlot px = map_pixel(P, P.unit0 + slot / kUnitPx, slot % kUnitPx);
     if (!px.valid) return false;
     const DV TL = ld3(P.cam.top_left), TR = ld3(P.cam.top_right), BL = ld3(P.cam.bottom_left), pos = ld3(P.cam.position);
     const double kx = (px.tap == 1u || px.tap == 4u) ? 0.6 : (px.tap == 3u ? 0.3 : 0.0);      // anti-aliasing taps, src/main.cpp:108-114
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64, QD_WF_WAVES) void wf_walk_kernel(const DScene S
     uint32_t* const ctl = P.wf_ctl + (size_t)gen * kWfGenWords;
     const size_t cap = P.wf_cap;
     const uint32_t n_in = gen == 0 ? P.n_units * kUnitPx
-                                   : min(__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), (uint32_t)cap);
+                                   : min(__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), P.wf_limit);
     uint32_t* const cursors = &ctl[wf_walk_cursor((uint32_t)slot) * kCtlStride];
     const uint64_t* const Q = P.wf_ray[gen & 1];
     uint64_t* const R = P.wf_res + (size_t)slot * kWfResWords * cap;
@@ -392,10 +392,10 @@ __global__ __launch_bounds__(64, QD_WF_SHADE_WAVES) void wf_shade_kernel(const D
     uint32_t* const ctl_next = ctl + kWfGenWords;
     const size_t cap = P.wf_cap;
     const uint32_t n_in = gen == 0 ? P.n_units * kUnitPx
-                                   : min(__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), (uint32_t)cap);
+                                   : min(__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), P.wf_limit);
     const uint64_t* const Q = P.wf_ray[gen & 1];
     WfAppender q;
-    q.base = P.wf_ray[(gen + 1) & 1]; q.cap = cap; q.count = &ctl_next[0]; q.err = P.error_flag; q.max_depth = P.max_depth; q.n_killed = 0;
+    q.base = P.wf_ray[(gen + 1) & 1]; q.cap = cap; q.limit = P.wf_limit; q.count = &ctl_next[0]; q.over = P.wf_over; q.max_depth = P.max_depth; q.n_killed = 0;
     q.lanes_below = (1ull << lane) - 1ull;
     Counters cnt; cnt.kd_nodes = cnt.tris = cnt.mesh_queries = 0; cnt.t_desc = cnt.t_leaf = cnt.t_a = cnt.t_b = cnt.t_c = cnt.t_d = 0;
     uint32_t n_rays = 0, n_shadow = 0, n_primary = 0;
@@ -471,4 +471,23 @@ __global__ __launch_bounds__(64, QD_WF_SHADE_WAVES) void wf_shade_kernel(const D
             }
         }
     }
+}
+
+// End of a band of the wavefront form (launch_wavefront), one thread per pixel slot of the band.  No append found its queue
+// full: the band's counters are added to the caller's.  Otherwise rays are missing from the band: its pixels are zeroed and
+// its counters dropped, and the launch that follows on the stream -- the one-kernel form on the same band, which does nothing
+// unless *P.wf_over is set -- renders it again; a pinned host word tells the library to keep the scene off this form.
+__global__ __launch_bounds__(64) void wf_band_end_kernel(const Params P) {
+    const uint32_t over = __hip_atomic_load(P.wf_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (over == 0u) {
+        if (blockIdx.x == 0 && threadIdx.x < 8u && P.user_stats && P.stats[threadIdx.x]) atomicAdd(&P.user_stats[threadIdx.x], P.stats[threadIdx.x]);
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(P.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
+    if (slot >= P.n_units * kUnitPx) return;
+    const PixelSlot px = map_pixel(P, P.unit0 + slot / kUnitPx, slot % kUnitPx);
+    if (!px.valid) return;
+    float* o = P.rgb + (P.mode == 0 ? (size_t)(px.out_idx / (uint32_t)P.rw) * P.pitch + (size_t)(px.out_idx % (uint32_t)P.rw) * 3 : (size_t)px.out_idx * 3);
+    o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
 }

@@ -66,6 +66,8 @@ def lib():
         L.qd_set_kd_refine.argtypes = [C.c_int, C.c_double]
         L.qd_set_pipeline.argtypes = [C.c_int]
         L.qd_set_kd_build.argtypes = [C.c_int]
+        L.qd_set_wavefront_budget.argtypes = [C.c_uint64, C.c_uint32]
+        L.qd_scene_wavefront_info.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_uint32), P(C.c_int)]
         L.qd_scene_schedule_info.argtypes = [C.c_void_p, P(C.c_int), P(C.c_double), P(C.c_double)]
         L.qd_prep_heightfield.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.qd_prep_highmap.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
@@ -121,6 +123,12 @@ def set_pipeline(pipeline):
     """0 = one persistent kernel with per-lane ray queues, 1 = wavefront pipeline (generations of rays in HBM queues),
     2 = the faster of the two, measured per scene (library default)."""
     _check(lib().qd_set_pipeline(pipeline), "qd_set_pipeline")
+
+
+def set_wavefront_budget(queue_bytes=0, max_entries=0):
+    """Bytes the ray queues of the wavefront form may take per working set (0 = 16 GB: frames beyond it are rendered in bands)
+    and, for tests, a cap on a queue's entries that the band sizes ignore (bands then overflow and are rendered again in place)."""
+    _check(lib().qd_set_wavefront_budget(queue_bytes, max_entries), "qd_set_wavefront_budget")
 
 
 def set_kd_refine(max_leaf_tris=2, step_cost=0.6):
@@ -282,6 +290,13 @@ class DeviceScene:
         f, a, b = C.c_int(), C.c_double(), C.c_double()
         _check(lib().qd_scene_schedule_info(self._h, C.byref(f), C.byref(a), C.byref(b)), "qd_scene_schedule_info")
         return {"form": int(f.value), "ns_per_pixel": [float(a.value), float(b.value)]}
+
+    def wavefront_info(self, width=None, height=None):
+        """Bands a frame of this size takes in the wavefront form, and whether a band ever outgrew its queues."""
+        st = self.host_scene.settings
+        b, o = C.c_uint32(), C.c_int()
+        _check(lib().qd_scene_wavefront_info(self._h, width or st.frame_width, height or st.frame_height, C.byref(b), C.byref(o)), "qd_scene_wavefront_info")
+        return {"bands": int(b.value), "overflowed": bool(o.value)}
 
     def setup_info(self):
         """Seconds qd_scene_create spent building the device KD trees / uploading the scene."""

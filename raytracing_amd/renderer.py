@@ -29,11 +29,13 @@ class FrameRenderer:
     last ray generations keep only a few waves busy and the next frame's pixels fill the rest of the chip."""
 
     def __init__(self, scene, tile=32, rank=0, world=1, local_device=0, frames_in_flight=1, collectives="rccl",
-                 force_collectives=False):
+                 force_collectives=False, dscene=None, comm=None, streams=None):
         """collectives: "rccl" = the library's own exchange step (qd_comm_*: grouped ncclSend / ncclRecv to rank 0 behind
         the C-ABI; the unique id travels over torch.distributed's process group), "torch" = torch.distributed.gather /
         broadcast, "none" = no exchange at all (rehearsals that time one rank's shard on a lone GPU).  force_collectives
-        runs the exchange even at world 1 (a one-rank communicator: tests)."""
+        runs the exchange even at world 1 (a one-rank communicator: tests).  dscene / comm: an existing DeviceScene of this
+        scene / an existing device.Comm to use instead of making new ones, streams: the HIP streams
+        of the slots (a second renderer for another frame size takes all three from the first: same working sets, same hardware queues)."""
         if not 1 <= frames_in_flight <= 7:
             raise ValueError("frames_in_flight must be 1..7 (libqdtrace keeps 8 working sets per scene, one of them the default stream's)")
         if collectives not in ("rccl", "torch", "none"):
@@ -42,16 +44,20 @@ class FrameRenderer:
         self.dev = torch.device("cuda", local_device)
         torch.cuda.set_device(self.dev)
         device.init(local_device)
-        self.dscene = device.DeviceScene(scene)
+        self._own_dscene, self._own_comm = dscene is None, False
+        self.dscene = dscene if dscene is not None else device.DeviceScene(scene)
         st = scene.settings
         self.W, self.H = st.frame_width, st.frame_height
         self.tpr = sharding.tiles_per_rank_padded(self.W, self.H, tile, world)
         self.F = frames_in_flight
         self.exchange = (world > 1 or force_collectives) and collectives != "none"
-        self.comm = None
-        if self.exchange and collectives == "rccl":
+        self.comm = comm if (self.exchange and collectives == "rccl") else None
+        if self.exchange and collectives == "rccl" and self.comm is None:
             self.comm = device.Comm(rank, world, exchange=self._exchange_id if world > 1 else None)
-        self.slots = [_Slot(self, torch.cuda.Stream(self.dev) if self.F > 1 else None) for _ in range(self.F)]
+            self._own_comm = True
+        if streams is not None and len(streams) != self.F:
+            raise ValueError("streams: one per frame in flight")
+        self.slots = [_Slot(self, (streams[i] if streams is not None else torch.cuda.Stream(self.dev)) if self.F > 1 else None) for i in range(self.F)]
         for sl in self.slots:
             if sl.stream is not None:
                 self.dscene.bind_stream(sl.stream.cuda_stream)
@@ -135,17 +141,12 @@ class FrameRenderer:
         """Untimed set-up: lets the library time both scheduling forms on this scene's real frames (qd_set_pipeline 2) so
         that the frames that follow run in the faster one.  The library times frames that ran alone on the GPU, so the
         frames here are rendered one at a time (submit, wait); each form needs two of them (the first loads its kernels).
-        A frame that outgrows the wavefront queues is dropped here (the library keeps such a scene on the one-kernel
-        form).  Every rank must call it, with the same count (the frames are gathered)."""
+        Every rank must call it, with the same count (the frames are gathered)."""
         for _ in range(frames):
             k = self.submit_frame()
             self.wait(k)
             torch.cuda.synchronize(self.dev)
-            try:
-                self.dscene.check()
-            except device.DeviceError as e:
-                if "wavefront form" not in str(e):
-                    raise
+            self.dscene.check()
 
     def wait(self, slot=None):
         """Host-wait for one slot's stream (or all of them) and return that slot's frame (rank 0) or None."""
@@ -195,6 +196,16 @@ class FrameRenderer:
 
     def check(self):
         self.dscene.check()
+
+    def close(self):
+        """Waits for this renderer's streams, then frees what it made itself (the RCCL communicator, the device scene)."""
+        torch.cuda.synchronize(self.dev)
+        if self._own_comm and self.comm is not None:
+            self.comm.close()
+        self.comm = None
+        if self._own_dscene and self.dscene is not None:
+            self.dscene.close()
+        self.dscene = None
 
     def quantize_bgr8(self):
         """8-bit BGR bottom-up rows of rank 0's frame, as Bitmap::SaveBMP lays them out (src/bitmap.cpp:209-217)."""

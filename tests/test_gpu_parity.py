@@ -577,12 +577,12 @@ def test_frame_renderer_runs_the_aa_pass_on_the_gathered_frame(load_scene):
 
 def test_first_frame_runs_in_the_form_the_prior_names(load_scene):
     """Before anything is measured (a caller that renders one image) the form comes from the scene: wavefront, unless the
-    tree is deep (asserted in test_full_size_bench_scene_matches_oracle) or the shader graph can queue more rays per pixel
-    than the wavefront queues are granted -- a 25-sample glossy floor gets them at 768x512 and not at 4K (8 per pixel there).
-    Either way the frame is the one a pinned form gives."""
+    tree is deep (asserted in test_full_size_bench_scene_matches_oracle).  A 25-sample glossy floor, whose queues outgrow
+    the memory budget at 4K, is rendered in bands there (test_wavefront_form_renders_a_big_glossy_frame_in_bands) and stays
+    on the form.  Either way the frame is the one a pinned form gives."""
     if os.environ.get("QD_PIPELINE") not in (None, "", "2"):
         pytest.skip("the scheduling form is pinned for this run")
-    for name, size, want in [("kdtree_teapot_lowres_env.qdmg", None, 1), ("hw9/dragon.qdmg", None, 1), ("hw9/dragon.qdmg", (3840, 2160), 0)]:
+    for name, size, want in [("kdtree_teapot_lowres_env.qdmg", None, 1), ("hw9/dragon.qdmg", None, 1), ("hw9/dragon.qdmg", (3840, 2160), 1)]:
         s = load_scene(name)
         st = s.settings
         old = (st.frame_width, st.frame_height, st.want_aa)
@@ -608,33 +608,106 @@ def test_first_frame_runs_in_the_form_the_prior_names(load_scene):
             st.frame_width, st.frame_height, st.want_aa = old
 
 
-def test_settle_survives_a_wavefront_overflow(load_scene):
-    """A 25-sample glossy floor at 4K: the wavefront queues get 9 entries per pixel of the 27 the shader graph can fill, so
-    the frames on which settle() tries that form overflow.  settle() drops them, the library keeps the scene on the
-    one-kernel form, and the frames that follow are clean."""
-    from raytracing_amd import renderer
-    if os.environ.get("QD_PIPELINE") not in (None, "", "2"):
-        pytest.skip("the scheduling form is pinned for this run")
+def test_wavefront_form_renders_a_big_glossy_frame_in_bands(load_scene):
+    """A 25-sample glossy floor at 4K asks for 28 queue entries per pixel, 41 GB: the wavefront form renders the frame in
+    bands that fit its 16 GB (qd_scene_wavefront_info), every band with its own loop over the generations, and the frame is
+    the one-kernel form's.  No queue overflows: nothing is reported, the scene stays eligible for the form."""
     s = load_scene("hw9/dragon.qdmg")
     st = s.settings
     old = (st.frame_width, st.frame_height, st.want_aa)
     st.frame_width, st.frame_height, st.want_aa = 3840, 2160, 0
     try:
+        ds = device.DeviceScene(s)
+        try:
+            assert ds.wavefront_info()["bands"] >= 2
+            device.set_pipeline(1)
+            a, _, sa = ds.render()
+            assert ds.schedule_info()["form"] == 1
+            device.set_pipeline(0)
+            b, _, sb = ds.render()
+            ds.check()
+            assert not ds.wavefront_info()["overflowed"]
+            assert sa["rays"] == sb["rays"] and sa["primary_rays"] == 3840 * 2160 and sa["shadow_rays"] == sb["shadow_rays"]
+            assert np.abs(a - b).max() <= COLOUR_TOL
+        finally:
+            device.set_pipeline(2)
+            ds.close()
+    finally:
+        st.frame_width, st.frame_height, st.want_aa = old
+
+
+@pytest.mark.parametrize("name", ["kdtree_fixed.qdmg", "lecture7_fixed.qdmg"])
+def test_wavefront_queues_cannot_fail_a_call(load_scene, name):
+    """No call fails over the wavefront queues.  With the queues cut to 20 000 entries (qd_set_wavefront_budget's test switch;
+    a generation of these frames has hundreds of thousands of rays) every band of the wavefront form overflows: the launch that follows each band on
+    the stream renders it again in the one-kernel form, so the synchronous call, the asynchronous frames and the AA pass all
+    return complete frames equal to the one-kernel form's, with its ray counts; nothing is reported by qd_scene_check, and
+    the scene is kept off the wavefront form afterwards.  With a budget of 2 MB the frame is cut into dozens of bands of
+    some 2 500 pixels (a band that lies on the glass teapot may well outgrow its four entries per pixel and take the
+    fallback; a frame-sized band averages over sky and floor): same frame, same ray counts."""
+    from raytracing_amd import renderer
+    s = load_scene(name)
+    old = _aa_settings(s, want_aa=0)
+    W, H = s.settings.frame_width, s.settings.frame_height
+    try:
+        ds = device.DeviceScene(s)
+        try:
+            device.set_pipeline(0)
+            ref, _, sref = ds.render()
+        finally:
+            ds.close()
+        # many small bands
+        device.set_pipeline(1)
+        device.set_wavefront_budget(2 << 20, 0)
+        ds = device.DeviceScene(s)
+        try:
+            assert ds.wavefront_info()["bands"] > 8
+            a, _, sa = ds.render()
+            ds.check()
+            assert ds.schedule_info()["form"] == 1
+            assert sa["rays"] == sref["rays"] and sa["depth_killed"] == sref["depth_killed"]
+            assert np.abs(a - ref).max() <= COLOUR_TOL
+        finally:
+            ds.close()
+        # every band overflows and is rendered again in place
+        device.set_wavefront_budget(0, 20000)
+        ds = device.DeviceScene(s)
+        try:
+            b, _, sb = ds.render(0, 0, W, H)
+            ds.check()                                           # nothing to report
+            assert ds.wavefront_info()["overflowed"]
+            assert sb["rays"] == sref["rays"] and sb["primary_rays"] == W * H and sb["shadow_rays"] == sref["shadow_rays"]
+            assert np.abs(b - ref).max() <= COLOUR_TOL
+        finally:
+            ds.close()
+        # asynchronous frames in flight + the AA pass under the same squeeze, library's own choice of form
+        device.set_pipeline(2)
         fr = renderer.FrameRenderer(s, tile=32, rank=0, world=1, local_device=0, frames_in_flight=2)
         try:
             fr.settle()
-            sched = fr.dscene.schedule_info()
-            assert sched["ns_per_pixel"][0] > 0. and sched["ns_per_pixel"][1] == 0.
             for _ in range(3):
                 k = fr.submit_frame()
-                assert fr.dscene.schedule_info()["form"] == 0
             frame = fr.wait(k).cpu().numpy()
             fr.check()
-            assert np.isfinite(frame).all() and frame.max() > 0.5
+            assert np.abs(frame - ref).max() <= COLOUR_TOL
+            assert fr.dscene.wavefront_info()["overflowed"] and fr.dscene.schedule_info()["form"] == 0     # demoted after its first try
+            aa = ref.copy()
+            fr.dscene.antialias(aa)
+            fr.check()
         finally:
-            fr.dscene.close()
+            fr.close()
+        device.set_wavefront_budget(0, 0)
+        ds = device.DeviceScene(s)
+        try:
+            aa_ref = ref.copy()
+            ds.antialias(aa_ref)
+        finally:
+            ds.close()
+        assert np.abs(aa - aa_ref).max() <= COLOUR_TOL
     finally:
-        st.frame_width, st.frame_height, st.want_aa = old
+        device.set_pipeline(2)
+        device.set_wavefront_budget(0, 0)
+        _aa_settings(s, **old)
 
 
 def test_adaptive_choice_times_both_forms_and_reports_setup(load_scene):
@@ -701,6 +774,7 @@ def test_frames_in_flight_give_the_single_frame(load_scene):
             tile, tpr = 32, sharding.tiles_per_rank_padded(W, H, 32, 1)
             streams = [torch.cuda.Stream() for _ in range(10)]
             shards = [torch.zeros((tpr, tile, tile, 3), dtype=torch.float32, device="cuda:0") for _ in streams]
+            torch.cuda.synchronize()                    # torch fills them on ITS stream: not ordered with the ten streams below
             for st_, sh in zip(streams, shards):
                 fr.dscene.render_tiles_async(sh.data_ptr(), tile, 0, 1, stream=st_.cuda_stream)
             torch.cuda.synchronize()
