@@ -123,7 +123,7 @@ def leg_1080p(args, scene, fr, rank, world, local, barrier):
     st.frame_width, st.frame_height = 1920, 1080
     try:
         f2 = renderer.FrameRenderer(scene, tile=args.tile, rank=rank, world=world, local_device=local, frames_in_flight=args.frames_in_flight,
-                                    dscene=fr.dscene, comm=fr.comm, streams=[sl.stream for sl in fr.slots])
+                                    dscene=fr.dscene, comm=fr.comms, streams=[sl.stream for sl in fr.slots])
         f2.settle()
         barrier()
         for _ in range(args.warmup):

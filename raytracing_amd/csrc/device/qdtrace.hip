@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstddef>
+#include <type_traits>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -118,6 +120,21 @@ QD_DEV const DScene& kernarg_scene() {
 }
 QD_DEV const Params& kernarg_params() {
     return *(const Params*)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + kParamsKernarg);
+}
+
+// What the two accessors above rely on, checked: both structs are plain bytes, and Params lies behind DScene where a struct of
+// the two would put it.  qd_init also launches kernarg_selftest_kernel once per device (sentinel values in both arguments, read
+// back through the accessors): a compiler or code-object change that moves the explicit arguments fails qd_init instead of
+// handing the callees garbage scene pointers.
+static_assert(std::is_trivially_copyable<DScene>::value && std::is_trivially_copyable<Params>::value, "kernel arguments are copied as bytes");
+struct KernargLayout { DScene s; Params p; };
+static_assert(offsetof(KernargLayout, p) == kParamsKernarg, "Params must follow DScene at its natural alignment in the kernel-argument segment");
+__global__ void kernarg_selftest_kernel(const DScene S, const Params P, uint32_t* out) {
+    const DScene& s2 = kernarg_scene();
+    const Params& p2 = kernarg_params();
+    bool ok = s2.n_nodes == S.n_nodes && s2.n_lights == S.n_lights && s2.nodes == S.nodes && s2.env_faces[5] == S.env_faces[5];
+    ok = ok && p2.W == P.W && p2.H == P.H && p2.n_units == P.n_units && p2.rgb == P.rgb && p2.wf_cap == P.wf_cap && p2.max_depth == P.max_depth;
+    if (threadIdx.x == 0) out[0] = ok ? 0x600dbeefu : 0xbadu;
 }
 
 QD_DEV uint64_t pack2f(float a, float b) { return (uint64_t)__float_as_uint(a) | ((uint64_t)__float_as_uint(b) << 32); }
@@ -1444,6 +1461,23 @@ extern "C" int qd_init(int device) {
         const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
         if (e != hipSuccess || !p) return set_err(std::string("qd_init: hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
         g_scratch_ptr[device] = (unsigned char*)p;
+    }
+    {   // kernarg_scene() / kernarg_params(): do they see what the kernel was given, on this device and code object?
+        static bool checked[kMaxDevices] = {};
+        if (device < kMaxDevices && !checked[device]) {
+            DScene S; Params P;
+            memset(&S, 0, sizeof S); memset(&P, 0, sizeof P);
+            S.n_nodes = 0x1234567u; S.n_lights = 77u; S.nodes = (const qd_node*)0x1000; S.env_faces[5] = -12345;
+            P.W = 4321; P.H = 8765; P.n_units = 0xabcdefu; P.rgb = (float*)0x2000; P.wf_cap = 0x13579bu; P.max_depth = 31u;
+            uint32_t* d_out = nullptr; uint32_t h_out = 0;
+            HIP_TRY(hipMalloc((void**)&d_out, sizeof(uint32_t)));
+            hipLaunchKernelGGL(kernarg_selftest_kernel, dim3(1), dim3(64), 0, nullptr, S, P, d_out);
+            const hipError_t e = hipMemcpy(&h_out, d_out, sizeof h_out, hipMemcpyDeviceToHost);
+            (void)hipFree(d_out);
+            if (e != hipSuccess) return set_err(std::string("qd_init: kernel-argument self-test: ") + hipGetErrorString(e));
+            if (h_out != 0x600dbeefu) return set_err("qd_init: kernel-argument self-test failed: the kernels' explicit arguments are not where kernarg_scene() / kernarg_params() read them");
+            checked[device] = true;
+        }
     }
     g_device = device;
     g_num_cu = prop.multiProcessorCount;

@@ -37,15 +37,29 @@ unsigned convert_to_8bit(double x) {
 
 // ------------------------------------------------------------------ BMP ----
 
+// The file is taken as bytes and its little-endian fields are picked by offset (BITMAPFILEHEADER at 0, BITMAPINFOHEADER at
+// 14: width 18, height 22, planes 26, bits per pixel 28, palette entries 46); no packed structs are overlaid on it.
 namespace {
-#pragma pack(push, 1)
-struct BmpFileHdr { int32_t fs; int32_t lzero; int32_t img_offset; };
-struct BmpInfoHdr {
-    int32_t ihdrsize; int32_t x, y; uint16_t planes; uint16_t bpp;
-    int32_t compression, size_image, ppm_x, ppm_y, colors, colors_important;
-};
-#pragma pack(pop)
-const uint16_t kBmpMagic = 19778;  // 'BM'
+constexpr size_t kBmpHeaderBytes = 14 + 40;
+
+uint32_t le16(const std::vector<unsigned char>& b, size_t at) { return (uint32_t)b[at] | ((uint32_t)b[at + 1] << 8); }
+int32_t le32(const std::vector<unsigned char>& b, size_t at) {
+    return (int32_t)((uint32_t)b[at] | ((uint32_t)b[at + 1] << 8) | ((uint32_t)b[at + 2] << 16) | ((uint32_t)b[at + 3] << 24));
+}
+void put16(std::vector<unsigned char>& b, size_t at, uint32_t v) { b[at] = (unsigned char)(v & 0xff); b[at + 1] = (unsigned char)((v >> 8) & 0xff); }
+void put32(std::vector<unsigned char>& b, size_t at, uint32_t v) { put16(b, at, v & 0xffffu); put16(b, at + 2, v >> 16); }
+
+bool read_whole_file(const char* path, std::vector<unsigned char>& out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    unsigned char chunk[1 << 16];
+    size_t n;
+    while ((n = fread(chunk, 1, sizeof chunk, f)) > 0) out.insert(out.end(), chunk, chunk + n);
+    fclose(f);
+    return true;
+}
+
+size_t padded_row_bytes(size_t width, size_t bytes_per_pixel) { return (width * bytes_per_pixel + 3) / 4 * 4; }
 
 struct FileCloser {
     FILE* f;
@@ -53,79 +67,69 @@ struct FileCloser {
 };
 }  // namespace
 
+// Bitmap::LoadBMP (src/bitmap.cpp:101-179): uncompressed 8 / 24 / 32 bits per pixel, one plane; rows stored bottom-up and
+// padded to four bytes; true-colour pixels are B, G, R; an 8-bit pixel indexes a palette whose entries the reference turns
+// into colours with Color(unsigned) (src/color.cpp:10-14: red from the LOW byte), i.e. with red and blue swapped relative to
+// the true-colour path -- kept, it only shows on colour palettes.
 bool load_bmp(const char* path, Image& img, std::string& err) {
     img = Image();
-    FILE* fp = fopen(path, "rb");
-    if (!fp) { err = std::string("loadBMP: can't open file `") + path + "'"; return false; }
-    FileCloser closer{fp};
-    uint16_t sign = 0;
-    BmpFileHdr hd; BmpInfoHdr hi;
-    if (!fread(&sign, 2, 1, fp) || sign != kBmpMagic) { err = std::string("loadBMP: `") + path + "' is not a BMP file"; return false; }
-    if (!fread(&hd, sizeof hd, 1, fp) || !fread(&hi, sizeof hi, 1, fp)) { err = "loadBMP: short header"; return false; }
-    if (!(hi.bpp == 8 || hi.bpp == 24 || hi.bpp == 32)) { err = "loadBMP: cannot handle this bit depth"; return false; }
-    if (hi.planes != 1) { err = "loadBMP: cannot load multichannel .bmp"; return false; }
-    if (hi.x <= 0 || hi.y <= 0) { err = "loadBMP: bad dimensions"; return false; }
+    std::vector<unsigned char> file;
+    if (!read_whole_file(path, file)) { err = std::string("loadBMP: can't open file `") + path + "'"; return false; }
+    if (file.size() < 2 || file[0] != 'B' || file[1] != 'M') { err = std::string("loadBMP: `") + path + "' is not a BMP file"; return false; }
+    if (file.size() < kBmpHeaderBytes) { err = "loadBMP: short header"; return false; }
+    const int32_t pixel_offset = le32(file, 10), width = le32(file, 18), height = le32(file, 22), palette_field = le32(file, 46);
+    const uint32_t planes = le16(file, 26), bits = le16(file, 28);
+    if (bits != 8 && bits != 24 && bits != 32) { err = "loadBMP: cannot handle this bit depth"; return false; }
+    if (planes != 1) { err = "loadBMP: cannot load multichannel .bmp"; return false; }
+    if (width <= 0 || height <= 0) { err = "loadBMP: bad dimensions"; return false; }
 
-    float palette[256][3] = {};
-    int toread = 0;
-    if (hi.bpp <= 8) {
-        toread = 1 << hi.bpp;
-        if (hi.colors) toread = hi.colors;
-        if (toread > 256) { err = "loadBMP: bad palette size"; return false; }
-        for (int i = 0; i < toread; ++i) {
-            uint32_t e = 0;
-            if (!fread(&e, 1, 4, fp)) { err = "loadBMP: short palette"; return false; }
-            // Color(unsigned): r from the low byte, b from bits 16..23 (src/color.cpp:10-14);
-            // the file stores B,G,R,0 so palette channels end up swapped vs the 24-bit path.
-            palette[i][0] = (e & 0xff) / 255.f;
-            palette[i][1] = ((e >> 8) & 0xff) / 255.f;
-            palette[i][2] = ((e >> 16) & 0xff) / 255.f;
-        }
+    std::vector<float> palette;                       // 3 floats per entry, in the order the reference's Color(unsigned) yields them
+    if (bits == 8) {
+        const int entries = palette_field ? palette_field : 256;
+        if (entries < 0 || entries > 256) { err = "loadBMP: bad palette size"; return false; }
+        if (file.size() < kBmpHeaderBytes + (size_t)entries * 4) { err = "loadBMP: short palette"; return false; }
+        palette.assign(256 * 3, 0.f);
+        for (int e = 0; e < entries; ++e)
+            for (int c = 0; c < 3; ++c) palette[(size_t)e * 3 + c] = file[kBmpHeaderBytes + (size_t)e * 4 + c] / 255.f;
     }
-    const long skip = hd.img_offset - (54 + toread * 4);
-    fseek(fp, skip, SEEK_CUR);
-    const int k = hi.bpp / 8;
-    int rowsz = hi.x * k;
-    if (rowsz % 4 != 0) rowsz = (rowsz / 4 + 1) * 4;
-    std::vector<unsigned char> row((size_t)rowsz);
-    img.make((uint32_t)hi.x, (uint32_t)hi.y);
-    for (int j = hi.y - 1; j >= 0; --j) {
-        if (!fread(row.data(), 1, (size_t)rowsz, fp)) { err = std::string("loadBMP: short read in `") + path + "'"; img = Image(); return false; }
-        for (int i = 0; i < hi.x; ++i) {
-            if (hi.bpp > 8)
-                img.set(i, j, row[i * k + 2] / 255.0f, row[i * k + 1] / 255.0f, row[i * k] / 255.0f);
-            else {
-                const float* p = palette[row[i * k]];
-                img.set(i, j, p[0], p[1], p[2]);
-            }
+    const size_t bpp = bits / 8, stride = padded_row_bytes((size_t)width, bpp);
+    if (pixel_offset < 0 || file.size() < (size_t)pixel_offset + stride * (size_t)height) {
+        err = std::string("loadBMP: short read in `") + path + "'";
+        return false;
+    }
+    img.make((uint32_t)width, (uint32_t)height);
+    for (int32_t file_row = 0; file_row < height; ++file_row) {
+        const unsigned char* px = file.data() + (size_t)pixel_offset + stride * (size_t)file_row;
+        const int y = height - 1 - file_row;          // the first stored row is the bottom one
+        for (int32_t x = 0; x < width; ++x, px += bpp) {
+            if (bits == 8) img.set(x, y, palette[(size_t)px[0] * 3], palette[(size_t)px[0] * 3 + 1], palette[(size_t)px[0] * 3 + 2]);
+            else img.set(x, y, px[2] / 255.0f, px[1] / 255.0f, px[0] / 255.0f);
         }
     }
     return true;
 }
 
+// Bitmap::SaveBMP (src/bitmap.cpp:181-220): 24 bits per pixel, rows bottom-up, B, G, R through ConvertTo8Bit (never sRGB).
 bool save_bmp(const char* path, const float* rgb, int w, int h, size_t pitch, std::string& err) {
-    FILE* fp = fopen(path, "wb");
-    if (!fp) { err = std::string("saveBMP: can't open `") + path + "'"; return false; }
-    FileCloser closer{fp};
-    int rowsz = w * 3;
-    if (rowsz % 4) rowsz += 4 - (rowsz % 4);
-    BmpFileHdr hd; BmpInfoHdr hi;
-    hd.fs = rowsz * h + 54; hd.lzero = 0; hd.img_offset = 54;
-    hi.ihdrsize = 40; hi.x = w; hi.y = h; hi.planes = 1; hi.bpp = 24;
-    hi.compression = hi.size_image = 0; hi.ppm_x = hi.ppm_y = 0; hi.colors = hi.colors_important = 0;
-    fwrite(&kBmpMagic, 2, 1, fp);
-    fwrite(&hd, sizeof hd, 1, fp);
-    fwrite(&hi, sizeof hi, 1, fp);
-    std::vector<unsigned char> row((size_t)rowsz, 0);
-    for (int y = h; y > 0; --y) {
-        const float* src = rgb + size_t(y - 1) * pitch;
-        for (int x = 0; x < w; ++x) {
-            row[x * 3 + 0] = (unsigned char)convert_to_8bit(src[x * 3 + 2]);
-            row[x * 3 + 1] = (unsigned char)convert_to_8bit(src[x * 3 + 1]);
-            row[x * 3 + 2] = (unsigned char)convert_to_8bit(src[x * 3 + 0]);
-        }
-        fwrite(row.data(), (size_t)rowsz, 1, fp);
+    const size_t stride = padded_row_bytes((size_t)w, 3);
+    std::vector<unsigned char> file(kBmpHeaderBytes + stride * (size_t)h, 0);
+    file[0] = 'B'; file[1] = 'M';
+    put32(file, 2, (uint32_t)file.size());            // file size
+    put32(file, 10, (uint32_t)kBmpHeaderBytes);       // where the pixels start
+    put32(file, 14, 40);                              // BITMAPINFOHEADER
+    put32(file, 18, (uint32_t)w); put32(file, 22, (uint32_t)h);
+    put16(file, 26, 1); put16(file, 28, 24);          // one plane, 24 bits; compression, sizes, resolution, palette: zero
+    for (int y = 0; y < h; ++y) {
+        unsigned char* out = file.data() + kBmpHeaderBytes + stride * (size_t)(h - 1 - y);
+        const float* in = rgb + (size_t)y * pitch;
+        for (int x = 0; x < w; ++x, in += 3, out += 3)
+            for (int c = 0; c < 3; ++c) out[c] = (unsigned char)convert_to_8bit(in[2 - c]);
     }
+    FILE* f = fopen(path, "wb");
+    if (!f) { err = std::string("saveBMP: can't open `") + path + "'"; return false; }
+    const bool ok = fwrite(file.data(), 1, file.size(), f) == file.size();
+    fclose(f);
+    if (!ok) { err = std::string("saveBMP: short write to `") + path + "'"; return false; }
     return true;
 }
 

@@ -51,17 +51,27 @@ class FrameRenderer:
         self.tpr = sharding.tiles_per_rank_padded(self.W, self.H, tile, world)
         self.F = frames_in_flight
         self.exchange = (world > 1 or force_collectives) and collectives != "none"
-        self.comm = comm if (self.exchange and collectives == "rccl") else None
-        if self.exchange and collectives == "rccl" and self.comm is None:
-            self.comm = device.Comm(rank, world, exchange=self._exchange_id if world > 1 else None)
-            self._own_comm = True
+        # One RCCL communicator PER SLOT: the gathers of frames in flight run on F different streams at once, and the operations
+        # of one communicator must not be in flight from several streams together (sharding.SlotSchedule).  `comm` (given or
+        # made here) is a list of F communicators, created in slot order on every rank; self.comm = slot 0's, which also
+        # carries the AA pass's broadcast / gather on the caller's stream.
+        self.comms = None
+        if self.exchange and collectives == "rccl":
+            if comm is not None:
+                self.comms = list(comm) if isinstance(comm, (list, tuple)) else [comm]
+                if len(self.comms) != self.F:
+                    raise ValueError("comm: one communicator per frame in flight")
+            else:
+                self.comms = [device.Comm(rank, world, exchange=self._exchange_id if world > 1 else None) for _ in range(self.F)]
+                self._own_comm = True
+        self.comm = self.comms[0] if self.comms else None
         if streams is not None and len(streams) != self.F:
             raise ValueError("streams: one per frame in flight")
         self.slots = [_Slot(self, (streams[i] if streams is not None else torch.cuda.Stream(self.dev)) if self.F > 1 else None) for i in range(self.F)]
         for sl in self.slots:
             if sl.stream is not None:
                 self.dscene.bind_stream(sl.stream.cuda_stream)
-        self._submitted = 0
+        self.schedule = sharding.SlotSchedule(self.F)
         s0 = self.slots[0]                                      # the single-frame interface works on slot 0
         self.shard, self.stats, self.frame, self.gathered = s0.shard, s0.stats, s0.frame, s0.gathered
 
@@ -83,12 +93,12 @@ class FrameRenderer:
         return bytes(t.cpu().numpy().tobytes())
 
     # The collectives, in one place (tests on a one-GPU box swap these two for host-staged gloo).
-    def _coll_gather(self, src, dst):
+    def _coll_gather(self, src, dst, slot=0):
         """src of every rank -> dst[r] on rank 0 (dst is None elsewhere).  Each peer's block goes straight to the
-        root over that peer's own xGMI link, not around a ring."""
+        root over that peer's own xGMI link, not around a ring.  On the communicator of `slot`."""
         stream = torch.cuda.current_stream(self.dev).cuda_stream
-        if self.comm is not None:
-            self.comm.gather_async(src.data_ptr(), dst.data_ptr() if self.rank == 0 else 0, src.numel(), stream=stream)
+        if self.comms is not None:
+            self.comms[slot].gather_async(src.data_ptr(), dst.data_ptr() if self.rank == 0 else 0, src.numel(), stream=stream)
             return
         import torch.distributed as dist
         dist.gather(src, list(dst.unbind(0)) if self.rank == 0 else None, dst=0)
@@ -100,15 +110,15 @@ class FrameRenderer:
         import torch.distributed as dist
         dist.broadcast(t, src=0)
 
-    def _gather_shards(self, sl):
-        self._coll_gather(sl.shard, sl.gathered)
+    def _gather_shards(self, sl, slot=0):
+        self._coll_gather(sl.shard, sl.gathered, slot)
 
     def gather(self, slot=0):
         """The one exchange step: compacted shards -> rank 0, then de-interleave."""
         sl = self.slots[slot]
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         if self.exchange:
-            self._gather_shards(sl)
+            self._gather_shards(sl, slot)
             if self.rank != 0:
                 return None
             src = sl.gathered
@@ -124,8 +134,7 @@ class FrameRenderer:
         """Enqueue one whole frame (trace + gather + de-interleave) on the next slot's stream and return the slot index;
         no host sync.  Every rank must submit frames in the same order (the gathers are collectives).  The frame of
         slot k is complete after wait(k); it is overwritten by the F-th submit after this one."""
-        k = self._submitted % self.F
-        self._submitted += 1
+        k = self.schedule.next()
         sl = self.slots[k]
         if sl.stream is None:
             self.render_shard(k)
@@ -200,9 +209,10 @@ class FrameRenderer:
     def close(self):
         """Waits for this renderer's streams, then frees what it made itself (the RCCL communicator, the device scene)."""
         torch.cuda.synchronize(self.dev)
-        if self._own_comm and self.comm is not None:
-            self.comm.close()
-        self.comm = None
+        if self._own_comm and self.comms:
+            for c in self.comms:
+                c.close()
+        self.comm = self.comms = None
         if self._own_dscene and self.dscene is not None:
             self.dscene.close()
         self.dscene = None

@@ -50,3 +50,25 @@ def aa_slice(n_listed, rank, world):
     per = (n_listed + world - 1) // world
     first = min(n_listed, rank * per)
     return per, first, min(n_listed, first + per) - first
+
+
+class SlotSchedule:
+    """Which slot (HIP stream, buffers, RCCL communicator) the n-th submitted frame uses: n % F.  Every rank walks the same
+    sequence, so the gathers -- collectives -- are issued in the same order everywhere; and a slot's gathers only ever
+    run on that slot's stream and communicator, i.e. strictly one after the other: no two operations of one communicator
+    are ever in flight together (RCCL, like NCCL, wants the operations of ONE communicator issued in one order on every
+    rank and not concurrently from several streams; different communicators may overlap).  `log` keeps what was issued,
+    for tests: (frame number, slot)."""
+
+    def __init__(self, frames_in_flight):
+        if frames_in_flight < 1:
+            raise ValueError("frames_in_flight must be >= 1")
+        self.F = frames_in_flight
+        self.submitted = 0
+        self.log = []
+
+    def next(self):
+        k = self.submitted % self.F
+        self.log = self.log[-255:] + [(self.submitted, k)]
+        self.submitted += 1
+        return k

@@ -859,7 +859,7 @@ def test_rccl_exchange_step_runs_at_world_one(load_scene):
         fr = renderer.FrameRenderer(s, tile=32, rank=0, world=1, local_device=0, frames_in_flight=3, collectives="rccl",
                                     force_collectives=True)
         try:
-            assert fr.comm is not None and fr.exchange
+            assert fr.comm is not None and fr.exchange and len(fr.comms) == 3        # one communicator per slot stream
             ref, _, _ = fr.dscene.render()
             slots = [fr.submit_frame() for _ in range(5)][-3:]
             for k in slots:
@@ -873,8 +873,7 @@ def test_rccl_exchange_step_runs_at_world_one(load_scene):
             assert np.abs(frame - ref_aa).max() <= SUM_ORDER_TOL
             assert np.abs(frame - ref).max() > 1e-3
         finally:
-            fr.comm.close()
-            fr.dscene.close()
+            fr.close()
     finally:
         _aa_settings(s, **old)
 

@@ -44,7 +44,7 @@ def _worker(rank, world, port, flight, out_path, aa=False):
     else:
         s.settings.want_aa = 0
     class HostGather(renderer.FrameRenderer):
-        def _coll_gather(self, src, dst):
+        def _coll_gather(self, src, dst, slot=0):
             torch.cuda.current_stream(self.dev).synchronize()
             mine = src.cpu()
             got = [torch.zeros_like(mine) for _ in range(self.world)] if self.rank == 0 else None

@@ -52,6 +52,47 @@ def test_two_rank_gather_reproduces_the_frame(tmp_path):
     assert np.load(out).all()
 
 
+def _order_worker(rank, world, port, F, n_frames, out_path):
+    """Two ranks drive frames through sharding.SlotSchedule (what FrameRenderer.submit_frame walks) with one gloo group per
+    slot standing in for the slot's RCCL communicator: each frame's shard is gathered on its slot's group, asynchronously
+    (several gathers in flight, as on the GPU streams), rank 1 deliberately lagging.  Rank 0 checks that every frame
+    arrived whole and that both ranks issued the same (frame, slot) sequence."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    groups = [dist.new_group(list(range(world))) for _ in range(F)]          # created in slot order on every rank
+    sched = sharding.SlotSchedule(F)
+    pending, ok = {}, True
+    for n in range(n_frames):
+        k = sched.next()
+        if k in pending:                                   # the slot's previous gather must be done before its buffers are reused
+            work, got, frame_no = pending.pop(k)
+            work.wait()
+            if rank == 0:
+                ok &= all(int(got[r][0]) == frame_no * 10 + r for r in range(world))
+        if rank == 1 and n % 2 == 0:
+            import time; time.sleep(0.01)
+        shard = torch.full((4,), float(n * 10 + rank))
+        got = [torch.zeros(4) for _ in range(world)] if rank == 0 else None
+        pending[k] = (dist.gather(shard, got, dst=0, group=groups[k], async_op=True), got, n)
+    for k, (work, got, frame_no) in pending.items():
+        work.wait()
+        if rank == 0:
+            ok &= all(int(got[r][0]) == frame_no * 10 + r for r in range(world))
+    logs = [None] * world
+    dist.all_gather_object(logs, sched.log)
+    if rank == 0:
+        np.save(out_path, np.array([ok, all(l == logs[0] for l in logs), logs[0] == [(n, n % F) for n in range(n_frames)]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_issue_the_gathers_of_frames_in_flight_in_one_order(tmp_path):
+    out = str(tmp_path / "order.npy")
+    mp.spawn(_order_worker, args=(2, _free_port(), 3, 11, out), nprocs=2, join=True)
+    assert np.load(out).all()
+
+
 def test_tile_ownership_is_a_partition():
     for (W, H, tile, world) in [(3840, 2160, 32, 8), (992, 744, 32, 3), (100, 60, 16, 4), (17, 9, 8, 2)]:
         seen = np.zeros((H, W), np.int32)
