@@ -536,13 +536,22 @@ QD_DEV PixelSlot map_pixel(const Params& P, uint32_t unit, uint32_t p) {
 // Persistent lanes: a lane that finishes its pixel immediately takes the next pixel of the wave's
 // current 8x8 unit (or of a freshly fetched unit), so no lane waits for the slowest pixel of a tile.
 // RICH: bitmap / Mandelbrot / procedural textures or bump maps present (see tex_sample); GEOM: see trace_nodes.
-// FLAT: the node loop and the shaders are inlined into the kernel, which then runs 3 waves per SIMD (168 registers) with
-// 12 far-child stack levels in LDS: the hit record and the IntersectionInfo stay in registers instead of crossing two calls
-// through scratch memory.  Pays for the copy without heightfield / CSG / extra-primitive / texture code (meshes + planes:
+// FLAT: the node loop and the shaders are inlined into the kernel: the hit record and the IntersectionInfo stay in registers
+// instead of crossing two calls through scratch memory.  Round 2 ran it 3 waves per SIMD (168 registers, 12 far-child stack
+// levels in LDS); with this round's kernel 4 waves per SIMD (128 registers, 8 levels in LDS so that 16 waves' LDS fits a CU)
+// measure 2 % faster in flight (10.70 against 10.94 ms per frame, twice), 2 waves 26 % slower.  Pays for the copy without heightfield / CSG / extra-primitive / texture code (meshes + planes:
 // +4.5 % on the 10 M triangle scene); the copies with more code in them are 20 - 50 % slower that way and keep the calls.
 // It contains no call at all -- not even the rare one for a Layered shader inside a layer, which alone costs 6 % -- so
 // launch() picks it only for scenes without such nesting.
-constexpr int kFlatWavesPerEU = 3, kFlatLdsStack = 12;
+#ifndef QD_FLAT_WAVES
+#define QD_FLAT_WAVES 4
+#endif
+#ifndef QD_FLAT_LDS_STACK
+#define QD_FLAT_LDS_STACK 8
+#endif
+constexpr int kFlatWavesPerEU = QD_FLAT_WAVES, kFlatLdsStack = QD_FLAT_LDS_STACK;
+// the per-lane ray queues are allocated for n_CU x 4 x QD_WAVES_PER_EU waves: a copy of the kernel must never start more
+static_assert(QD_FLAT_WAVES >= 1 && QD_FLAT_WAVES <= QD_WAVES_PER_EU, "the call-free kernel copy cannot run more waves per SIMD than the queues are allocated for");
 template <bool STATS, int GEOM, bool RICH, bool FLAT = false>
 __global__ __launch_bounds__(64, FLAT ? kFlatWavesPerEU : QD_WAVES_PER_EU) void trace_kernel(const DScene S, const Params P) {
     if (P.cond && __hip_atomic_load(P.cond, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;      // a fallback launch with nothing to fall back for
@@ -1349,7 +1358,7 @@ int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hi
     P.list_cap = w->list_cap;
     HIP_TRY(hipMemsetAsync(w->queue_ctr, 0, (size_t)(fallback ? 1 : kPasses) * kPassWords * sizeof(uint32_t), stream));
     if (!fallback) HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));       // the kernel adds colours into it
-    // the copy for meshes + planes without texture code runs 3 waves per SIMD (FLAT, see trace_kernel): fewer persistent waves
+    // the copy for meshes + planes without texture code (FLAT, see trace_kernel) may run fewer waves per SIMD than the others
     const bool flat = !g_counting && (s->geom_mask & 15) == 0 && !s->nested_layered;
     const uint32_t max_blocks = flat ? s->n_lanes / 64 / (uint32_t)QD_WAVES_PER_EU * (uint32_t)kFlatWavesPerEU : s->n_lanes / 64;
     const int n_passes = fallback ? 1 : kPasses;
