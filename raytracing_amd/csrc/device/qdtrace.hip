@@ -537,17 +537,18 @@ QD_DEV PixelSlot map_pixel(const Params& P, uint32_t unit, uint32_t p) {
 // current 8x8 unit (or of a freshly fetched unit), so no lane waits for the slowest pixel of a tile.
 // RICH: bitmap / Mandelbrot / procedural textures or bump maps present (see tex_sample); GEOM: see trace_nodes.
 // FLAT: the node loop and the shaders are inlined into the kernel: the hit record and the IntersectionInfo stay in registers
-// instead of crossing two calls through scratch memory.  Round 2 ran it 3 waves per SIMD (168 registers, 12 far-child stack
-// levels in LDS); with this round's kernel 4 waves per SIMD (128 registers, 8 levels in LDS so that 16 waves' LDS fits a CU)
-// measure 2 % faster in flight (10.70 against 10.94 ms per frame, twice), 2 waves 26 % slower.  Pays for the copy without heightfield / CSG / extra-primitive / texture code (meshes + planes:
+// instead of crossing two calls through scratch memory.  It runs 3 waves per SIMD (168 registers, 12 far-child stack levels in
+// LDS).  4 waves per SIMD (128 registers, 8 levels in LDS so that 16 waves' LDS fits a CU) measure 2 - 3 % faster in flight (10.62
+// against 10.97 ms per frame) but spill: HBM traffic per frame 21.7 -> 33.2 GB (writes 5.0 -> 9.7 GB, PMC), 1.9 x the algorithmic
+// bytes instead of 1.26 x -- not worth it; 2 waves are 26 % slower.  Pays for the copy without heightfield / CSG / extra-primitive / texture code (meshes + planes:
 // +4.5 % on the 10 M triangle scene); the copies with more code in them are 20 - 50 % slower that way and keep the calls.
 // It contains no call at all -- not even the rare one for a Layered shader inside a layer, which alone costs 6 % -- so
 // launch() picks it only for scenes without such nesting.
 #ifndef QD_FLAT_WAVES
-#define QD_FLAT_WAVES 4
+#define QD_FLAT_WAVES 3
 #endif
 #ifndef QD_FLAT_LDS_STACK
-#define QD_FLAT_LDS_STACK 8
+#define QD_FLAT_LDS_STACK 12
 #endif
 constexpr int kFlatWavesPerEU = QD_FLAT_WAVES, kFlatLdsStack = QD_FLAT_LDS_STACK;
 // the per-lane ray queues are allocated for n_CU x 4 x QD_WAVES_PER_EU waves: a copy of the kernel must never start more
