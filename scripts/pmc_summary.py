@@ -26,6 +26,8 @@ tot_fetch = tot_write = 0.0
 for fam, d in res.items():
     n_launch = max(cnt[fam].values())
     per_frame = 3 if fam == "trace_kernel" else None
+    if fam == "trace_kernel" and "wf_shade_kernel" in res:
+        continue              # the in-stream fallback launches behind the wavefront bands (they return at once): not a kernel of this frame
     if fam != "trace_kernel":
         # launches per frame of this family: from the bench line (walk launches = shade launches x KD-mesh nodes)
         shade = max(cnt["wf_shade_kernel"].values()) if "wf_shade_kernel" in cnt else n_launch
