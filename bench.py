@@ -32,10 +32,19 @@ MAX_CLOCK_HZ = 2.4e9      # MI355X_MICROARCH.md: max clock (the chip holds less 
 
 
 def lib_sha256():
+    """Identity of the device library build: sha256 over its sources (csrc/device/*, include/qdtrace.h) -- the same for every
+    rebuild of the same tree, unlike the bytes of the .so.  None for a development build loaded through device.use_library."""
     import hashlib
     from raytracing_amd import device
-    path = device._LIB_OVERRIDE or os.path.join(ROOT, "raytracing_amd", "lib", "libqdtrace.so")
-    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+    if device._LIB_OVERRIDE:
+        return None
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "raytracing_amd", "csrc", "device")
+    for f in sorted(os.listdir(src)) + [os.path.join(ROOT, "include", "qdtrace.h")]:
+        p = f if os.path.isabs(f) else os.path.join(src, f)
+        if os.path.isfile(p):
+            h.update(os.path.basename(p).encode()); h.update(open(p, "rb").read())
+    return h.hexdigest()
 
 
 def profiled_counters(key):
@@ -52,8 +61,8 @@ def profiled_counters(key):
     if not e:
         return None, "no PMC profile of this workload under profiles/"
     if e.get("lib_sha256") != lib_sha256():
-        return None, f"stale: profiles/hbm_traffic.json[{key}] was collected on build {e.get('build')} (another libqdtrace.so than this run's)"
-    return e, f"profiles/hbm_traffic.json[{key}], build {e.get('build')}, libqdtrace.so sha256 {e['lib_sha256'][:12]}: {e.get('source', '')}"
+        return None, f"stale: profiles/hbm_traffic.json[{key}] was collected on build {e.get('build')} (other device sources than this run's)"
+    return e, f"profiles/hbm_traffic.json[{key}], build {e.get('build')}, device sources sha256 {e['lib_sha256'][:12]}: {e.get('source', '')}"
 
 
 def build_scene(args):
