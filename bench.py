@@ -132,7 +132,7 @@ def leg_1080p(args, scene, fr, rank, world, local, barrier):
     st.frame_width, st.frame_height = 1920, 1080
     try:
         f2 = renderer.FrameRenderer(scene, tile=args.tile, rank=rank, world=world, local_device=local, frames_in_flight=args.frames_in_flight,
-                                    dscene=fr.dscene, comm=fr.comms, streams=[sl.stream for sl in fr.slots])
+                                    dscene=fr.dscene, comm=fr.comms, streams=[sl.stream for sl in fr.slots], collectives=args.collectives)
         f2.settle()
         barrier()
         for _ in range(args.warmup):
@@ -173,6 +173,8 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames enqueued at a time, one HIP stream each (1 = strictly one after the other; 0 = by shard size: 4 up to 4 GPUs, 6 beyond)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--collectives", default="rccl", choices=["rccl", "host"],
+                    help="'host': the exchange staged through host memory over gloo -- a rehearsal of N ranks sharing ONE GPU (RCCL refuses two ranks per device); not a measurement")
     ap.add_argument("--no-1080p", action="store_true", help="skip the 1920x1080 leg that follows a 3840x2160 run")
     ap.add_argument("--pipeline", type=int, default=None, help="qd_set_pipeline: 0 = one kernel with per-lane queues, 1 = wavefront, 2 = the faster of the two, measured (library default)")
     ap.add_argument("--kd-build", type=int, default=None, help="qd_set_kd_build: 1 = device tree by SAH from the triangles, 0 = the caller's planes + refined leaves")
@@ -189,6 +191,8 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if args.collectives == "host":
+        local = 0                                         # every rank on the one GPU
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -218,7 +222,7 @@ def main():
     t_host_scene = time.perf_counter() - t_setup
     t_setup = time.perf_counter()
     fr = renderer.FrameRenderer(scene, tile=args.tile, rank=rank, world=world, local_device=local,
-                                frames_in_flight=args.frames_in_flight)
+                                frames_in_flight=args.frames_in_flight, collectives=args.collectives)
     t_device_scene = time.perf_counter() - t_setup     # qd_scene_create: upload + device KD tree build, untimed set-up
     W, H = fr.W, fr.H
 
@@ -311,7 +315,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "width": W, "height": H, "rays_per_frame": int(rays_frame),
                        "primary_rays": int(rays_local[1].item()), "shadow_rays": int(rays_local[2].item()),
-                       "parallelism": f"tiles{args.tile}x{args.tile} interleaved over {world} rank(s), RCCL gather to rank 0",
+                       "parallelism": f"tiles{args.tile}x{args.tile} interleaved over {world} rank(s), " + ("RCCL gather to rank 0" if args.collectives == "rccl" else "HOST-STAGED gloo gather (rehearsal on one GPU, not a measurement)"),
                        "frames_in_flight": args.frames_in_flight, "schedule": sched,
                        "setup_s": {"host_scene": round(t_host_scene, 2), "device_scene": round(t_device_scene, 2), **{k: round(v, 2) for k, v in fr.dscene.setup_info().items()}}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -32,14 +32,17 @@ class FrameRenderer:
                  force_collectives=False, dscene=None, comm=None, streams=None):
         """collectives: "rccl" = the library's own exchange step (qd_comm_*: grouped ncclSend / ncclRecv to rank 0 behind
         the C-ABI; the unique id travels over torch.distributed's process group), "torch" = torch.distributed.gather /
-        broadcast, "none" = no exchange at all (rehearsals that time one rank's shard on a lone GPU).  force_collectives
+        broadcast, "host" = the same exchange staged through host memory over a gloo group (a rehearsal of N ranks that SHARE
+        one GPU, where RCCL refuses two ranks per device: every collective first drains the stream, so nothing overlaps),
+        "none" = no exchange at all (rehearsals that time one rank's shard on a lone GPU).  force_collectives
         runs the exchange even at world 1 (a one-rank communicator: tests).  dscene / comm: an existing DeviceScene of this
         scene / an existing device.Comm to use instead of making new ones, streams: the HIP streams
         of the slots (a second renderer for another frame size takes all three from the first: same working sets, same hardware queues)."""
         if not 1 <= frames_in_flight <= 7:
             raise ValueError("frames_in_flight must be 1..7 (libqdtrace keeps 8 working sets per scene, one of them the default stream's)")
-        if collectives not in ("rccl", "torch", "none"):
-            raise ValueError("collectives must be 'rccl', 'torch' or 'none'")
+        if collectives not in ("rccl", "torch", "host", "none"):
+            raise ValueError("collectives must be 'rccl', 'torch', 'host' or 'none'")
+        self.collectives = collectives
         self.scene, self.tile, self.rank, self.world = scene, tile, rank, world
         self.dev = torch.device("cuda", local_device)
         torch.cuda.set_device(self.dev)
@@ -101,6 +104,14 @@ class FrameRenderer:
             self.comms[slot].gather_async(src.data_ptr(), dst.data_ptr() if self.rank == 0 else 0, src.numel(), stream=stream)
             return
         import torch.distributed as dist
+        if self.collectives == "host":
+            torch.cuda.current_stream(self.dev).synchronize()
+            mine = src.cpu()
+            got = [torch.zeros_like(mine) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(mine, got, dst=0)
+            if self.rank == 0:
+                dst.copy_(torch.stack(got))
+            return
         dist.gather(src, list(dst.unbind(0)) if self.rank == 0 else None, dst=0)
 
     def _coll_broadcast(self, t):
@@ -108,6 +119,12 @@ class FrameRenderer:
             self.comm.broadcast_async(t.data_ptr(), t.numel(), stream=torch.cuda.current_stream(self.dev).cuda_stream)
             return
         import torch.distributed as dist
+        if self.collectives == "host":
+            torch.cuda.current_stream(self.dev).synchronize()
+            h = t.cpu()
+            dist.broadcast(h, src=0)
+            t.copy_(h)
+            return
         dist.broadcast(t, src=0)
 
     def _gather_shards(self, sl, slot=0):
