@@ -710,6 +710,42 @@ def test_wavefront_queues_cannot_fail_a_call(load_scene, name):
         _aa_settings(s, **old)
 
 
+def test_frame_begun_ahead_survives_an_overflow_and_a_render_in_between(load_scene):
+    """qd_frame_begin in the wavefront form with queues that every band outgrows (the test switch of
+    qd_set_wavefront_budget), then a qd_render on the same stream -- same working set, same error word -- before the first
+    read: the frame read back is the complete frame (the band was rendered again in place, on the stream), the rectangle
+    call is right too, and nothing is reported."""
+    s = load_scene("kdtree_fixed.qdmg")
+    old = _aa_settings(s, want_aa=0)
+    W, H = s.settings.frame_width, s.settings.frame_height
+    try:
+        device.set_pipeline(0)
+        ds = device.DeviceScene(s)
+        try:
+            ref, _, sref = ds.render()
+        finally:
+            ds.close()
+        device.set_pipeline(1)
+        device.set_wavefront_budget(0, 20000)
+        ds = device.DeviceScene(s)
+        try:
+            ds.frame_begin()
+            part, _, pst = ds.render(560, 400, 688, 496)             # on the teapot: overflows its queues as well
+            frame = ds.frame_read_rect(0, 0, W, H)
+            st = ds.frame_end()
+            ds.check()
+            assert ds.wavefront_info()["overflowed"]
+            assert st["rays"] == sref["rays"] and st["primary_rays"] == W * H
+            assert np.abs(frame - ref).max() <= COLOUR_TOL
+            assert pst["primary_rays"] == 128 * 96 and np.abs(part - ref[400:496, 560:688]).max() <= COLOUR_TOL
+        finally:
+            ds.close()
+    finally:
+        device.set_pipeline(2)
+        device.set_wavefront_budget(0, 0)
+        _aa_settings(s, **old)
+
+
 def test_adaptive_choice_times_both_forms_and_reports_setup(load_scene):
     """qd_set_pipeline(2): after FrameRenderer.settle() both scheduling forms have a measured ns-per-pixel figure (lone
     frames, two per form); the frames that follow -- in flight, untimed -- run in the faster one (kdtree_fixed: the forms
