@@ -966,7 +966,8 @@ bool g_counting = false;
 int g_pipeline = 2;           // qd_set_pipeline: 0 = one persistent kernel with per-lane LIFO queues, 1 = wavefront pipeline (wavefront.h), 2 = the faster of the two, measured per scene
 int g_refine_leaf = 2;        // qd_set_kd_refine
 double g_refine_cost = 0.6;
-uint64_t g_wf_budget = 16ull << 30;   // qd_set_wavefront_budget: bytes of ray queues per working set (wavefront form); for tests, a cap on the
+constexpr uint64_t kWfDefaultBudget = 16ull << 30;
+uint64_t g_wf_budget = kWfDefaultBudget;   // qd_set_wavefront_budget: bytes of ray queues per working set (wavefront form); for tests, a cap on the
 uint32_t g_wf_max_entries = 0;        // entries of a queue that the band sizes do NOT take into account (0 = none): bands then overflow
 int g_kd_build = 1;           // qd_set_kd_build: 0 = the caller's planes, leaves refined; 1 = whole tree by the surface-area heuristic, built on the device (kdbuild.h); 2 = the same by host threads (kdrefine.h)
 
@@ -1076,8 +1077,9 @@ struct qd_scene {
     FormSample sample;                   // the latest frame, if it started alone
     bool serial_caller = false;          // the latest sample was accepted: the caller waits for its frames
     uint64_t form_frames = 0;
-    bool wavefront_overflowed = false;   // a band of the wavefront form outgrew its queues once: the scene stays on the one-kernel form
-    uint32_t* host_flag = nullptr;       // pinned host word the device sets when that happens (read without waiting), and its device address
+    int wf_level = 0;                    // sizing of the wavefront queues (wavefront_plan): 0 = one band, optimistic; 1 = by the shader graph, in bands
+    bool wavefront_overflowed = false;   // a band of level 1 outgrew its queues: the scene stays on the one-kernel form
+    uint32_t* host_flag = nullptr;       // two pinned host words the device sets when a band of level 0 / 1 overflows (read without waiting), and their device address
     uint32_t* host_flag_dev = nullptr;
     int last_form = 0;                   // form of the most recent launch (qd_scene_schedule_info)
     uint64_t kd_nodes = 0, kd_refs = 0, kd_leaves = 0, kd_max_leaf = 0;   // device tree after refinement
@@ -1165,10 +1167,16 @@ constexpr uint32_t kWfMaxGens = 67;          // generations a frame may have: ma
 
 // Ray queues of the wavefront form for a launch over n_slots pixel slots: entries per queue (`cap`) and pixel slots per
 // band.  A generation holds at most (rays of the one before) x (tasks queued per hit); generation 1 is bounded by
-// pixels x spawn0, later ones shrink in every scene measured (rays leave the scene faster than glass doubles them), so a band
-// is granted max(4, spawn0 + 1) entries per pixel slot.  Within 16 GB per working set: a frame that asks for more (a 25-sample
-// glossy floor at 4K: 28 entries per pixel, 41 GB) is rendered in BANDS of whole 8 x 8 units, one after the other on the
-// stream, each with its own loop over the generations and the same queues.
+// pixels x spawn0, later ones shrink in every scene measured (rays leave the scene faster than glass doubles them), so the
+// shader graph asks for max(4, spawn0 + 1) entries per pixel slot.  Within 16 GB per working set:
+//   level 0 (a scene's first frames): ONE band whatever the graph asks for -- what fits the budget, at least 8 entries per
+//            pixel slot.  A 25-sample glossy sphere that covers a tenth of a 4K frame asks for 27 per pixel and fills 5; bands
+//            would only add generation tails to such a frame (lecture7 at 4K: 6.0 against 7.0 ms);
+//   level 1 (after a frame of level 0 outgrew its queues -- it was rendered again in place, see launch_wavefront): by the
+//            shader graph, a frame that asks for more than the budget (a 25-sample glossy FLOOR at 4K: 28 entries per pixel,
+//            41 GB) in BANDS of whole 8 x 8 units, one after the other on the stream, each with its own loop over the
+//            generations and the same queues.  A band that overflows at this level takes the scene off the form.
+// An explicit qd_set_wavefront_budget is a hard limit: level 1 from the start.
 struct WfPlan { uint64_t cap; uint64_t band_slots; };
 WfPlan wavefront_plan(const qd_scene* s, uint64_t n_slots) {
     const size_t n_kd = std::max<size_t>(1, s->kd_node_list.size());
@@ -1180,6 +1188,11 @@ WfPlan wavefront_plan(const qd_scene* s, uint64_t n_slots) {
     want = std::max<uint64_t>(want, std::min<uint64_t>(n_slots * 32, 8u << 20));
     want = std::max<uint64_t>(want, 1u << 16);
     WfPlan p;
+    if (s->wf_level == 0 && std::max(budget, n_slots * 8) < (1ull << 31)) {
+        p.cap = std::min(want, std::max(budget, n_slots * 8));
+        p.band_slots = n_slots;
+        return p;
+    }
     p.cap = std::min(want, budget);
     p.band_slots = p.cap >= n_slots * demand ? n_slots : std::max<uint64_t>(kUnitPx, p.cap / demand / kUnitPx * kUnitPx);
     return p;
@@ -1226,7 +1239,7 @@ int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hip
     P.wf_limit = g_wf_max_entries ? std::min<uint32_t>(P.wf_cap, std::max<uint32_t>(g_wf_max_entries, 64u)) : P.wf_cap;
     P.error_flag = s->error_flag + (w - s->sets);
     P.wf_over = w->wf_ctl + kWfTail;
-    P.host_flag = s->host_flag_dev;
+    P.host_flag = s->host_flag_dev + (s->wf_level ? 1 : 0);           // which level's frame it was that overflowed
     unsigned long long* const band_stats = (unsigned long long*)(w->wf_ctl + kWfTail + kCtlStride);
     unsigned long long* const user_stats = P.stats;
     HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));
@@ -1313,6 +1326,15 @@ int prior_form(const qd_scene* s, uint64_t) {
     return 1;
 }
 
+// The pinned words the device sets when a band overflows: level 0 -> size by the shader graph from now on; level 1 -> off the form.
+// (An explicit queue budget or entry limit is a hard limit: level 1 at once.)
+void read_overflow_words(qd_scene* s) {
+    if (!s->host_flag) return;
+    const volatile uint32_t* f = s->host_flag;
+    if (s->wf_level == 0 && (f[0] || g_wf_budget != kWfDefaultBudget || g_wf_max_entries)) s->wf_level = 1;
+    if (f[1]) s->wavefront_overflowed = true;
+}
+
 int choose_form(qd_scene* s, uint64_t n_slots) {
     if (g_pipeline != 2) return g_pipeline;
     if (s->kd_node_list.size() > kWfMaxKdNodes || s->wavefront_overflowed) return 0;
@@ -1330,7 +1352,7 @@ int launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream) {
     WorkSet* w = nullptr;
     if (acquire_set(s, stream, max_depth, &w)) return -1;
     read_sample(s, true);
-    if (s->host_flag && *(volatile uint32_t*)s->host_flag) s->wavefront_overflowed = true;     // a band outgrew its queues (and was rendered again in place)
+    read_overflow_words(s);     // a band outgrew its queues (and was rendered again in place)
     const int form = choose_form(s, (uint64_t)P.n_units * kUnitPx);
     bool alone = g_pipeline == 2;                         // does this frame start on a drained GPU (as far as this scene goes)?
     for (auto& c : s->sets) if (alone && c.t1 && hipEventQuery(c.t1) != hipSuccess) alone = false;
@@ -1798,9 +1820,9 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
     if (!rc && hipMalloc((void**)&s->stats, (24 + 6 * 4096) * sizeof(unsigned long long)) != hipSuccess) rc = set_err("hipMalloc(stats) failed");
     if (!rc && hipMalloc((void**)&s->error_flag, kErrFlags * sizeof(int)) != hipSuccess) rc = set_err("hipMalloc(error flags) failed");
     if (!rc && hipMemset(s->error_flag, 0, kErrFlags * sizeof(int)) != hipSuccess) rc = set_err("hipMemset failed");
-    if (!rc && (hipHostMalloc((void**)&s->host_flag, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+    if (!rc && (hipHostMalloc((void**)&s->host_flag, 2 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
                 hipHostGetDevicePointer((void**)&s->host_flag_dev, s->host_flag, 0) != hipSuccess)) rc = set_err("hipHostMalloc(overflow word) failed");
-    if (!rc) *s->host_flag = 0u;
+    if (!rc) { s->host_flag[0] = 0u; s->host_flag[1] = 0u; }
     if (!rc) {                                   // working set of the default stream, so that a first render allocates nothing
         WorkSet* w = nullptr;
         rc = acquire_set(s, nullptr, desc->settings.max_trace_depth, &w);
@@ -2265,7 +2287,7 @@ extern "C" int qd_scene_check(qd_scene* s) {
     HIP_TRY(hipMemcpy(f, s->error_flag, sizeof f, hipMemcpyDeviceToHost));
     bool any = false;
     for (int i = 0; i < kErrFlags; ++i) any |= f[i] != 0;
-    if (s->host_flag && *(volatile uint32_t*)s->host_flag) s->wavefront_overflowed = true;
+    read_overflow_words(s);
     if (any) {
         (void)hipMemset(s->error_flag, 0, sizeof f);
         return set_err("ray queue overflow on device");
@@ -2274,7 +2296,7 @@ extern "C" int qd_scene_check(qd_scene* s) {
 }
 
 extern "C" int qd_set_wavefront_budget(uint64_t queue_bytes, uint32_t max_entries) {
-    g_wf_budget = queue_bytes ? queue_bytes : (16ull << 30);
+    g_wf_budget = queue_bytes ? queue_bytes : kWfDefaultBudget;
     g_wf_max_entries = max_entries;
     return 0;
 }
@@ -2284,9 +2306,9 @@ extern "C" int qd_scene_wavefront_info(const qd_scene* cs, int width, int height
     qd_scene* s = const_cast<qd_scene*>(cs);
     std::lock_guard<std::mutex> lock(s->mu);
     const uint64_t n_slots = (uint64_t)((width + kUnitSide - 1) / kUnitSide) * (uint64_t)((height + kUnitSide - 1) / kUnitSide) * kUnitPx;
+    read_overflow_words(s);
     const WfPlan plan = wavefront_plan(s, n_slots);
     if (bands) *bands = (uint32_t)((n_slots + plan.band_slots - 1) / plan.band_slots);
-    if (s->host_flag && *(volatile uint32_t*)s->host_flag) s->wavefront_overflowed = true;
     if (overflowed) *overflowed = s->wavefront_overflowed ? 1 : 0;
     return 0;
 }
