@@ -413,11 +413,13 @@ int qd_set_counting(int on);
  * 0 = one persistent kernel, every lane with its own LIFO queue of ray tasks (memory bounded by queue depth x lanes);
  * 1 = wavefront pipeline: generations of rays in HBM queues, a KD walk kernel per mesh node that refills idle lanes inside
  *     its loop and a full-width shading kernel per generation.  Queues hold max(4, tasks per hit + 1) entries per pixel
- *     within 16 GB per working set; a frame that asks for more (25 glossy samples at 4K) is rendered in bands of whole
- *     8 x 8 units, one after the other on the stream.  No call fails over the queues: a generation that still outgrows
- *     them (glass that keeps doubling) sets a device word, and the launch that follows every band on the stream -- the
- *     band once more in form 0, which returns at once when the word is clear -- renders that band again in place; the
- *     scene then stays on form 0 (qd_scene_wavefront_info tells).  The frame is complete and correct either way;
+ *     within 16 GB per working set.  A frame that asks for more (25 glossy samples at 4K) is first tried in one band with
+ *     what fits (at least 8 entries per pixel; most such frames use a fraction of what they may ask for), and once a
+ *     frame has outgrown that the scene's frames are rendered in bands of whole 8 x 8 units, one after the other on the
+ *     stream.  No call fails over the queues: a generation that outgrows them sets a device word, and the launch that
+ *     follows every band on the stream -- the band once more in form 0, which returns at once when the word is clear --
+ *     renders that band again in place; a scene whose bands still overflow (glass that keeps doubling) then stays on form 0
+ *     (qd_scene_wavefront_info tells).  The frame is complete and correct either way;
  * 2 = (default) the faster of the two for the scene at hand: each form is timed with HIP events on frames of the scene that
  *     ran alone on the GPU (enqueued when the scene's earlier work had finished, finished before the next launch; read
  *     without waiting), a form's first such frame is dropped, the faster form renders, and a caller that waits for its
@@ -434,9 +436,11 @@ int qd_set_pipeline(int pipeline);
 int qd_scene_schedule_info(const qd_scene* scene, int* last_form, double* ns_per_pixel_form0, double* ns_per_pixel_form1);
 
 /* Replaces: nothing in the reference.  Memory the ray queues of form 1 may take per working set (default 16 GB; 0 = default):
- * a frame beyond the budget is rendered in bands.  max_entries, for tests (0 = off): a cap on the entries of a queue that the
- * band sizes do not take into account, so that bands overflow and the in-stream fallback runs.  qd_scene_wavefront_info: the bands a width x height frame of this scene takes, and whether a
- * band of the scene ever outgrew its queues (it was rendered again in form 0 on the spot, and the scene stays on form 0). */
+ * a frame beyond the budget is rendered in bands (with the default budget only after a first frame of the scene outgrew one
+ * band, see qd_set_pipeline; an explicit budget is a hard limit from the first frame).  max_entries, for tests (0 = off): a cap
+ * on the entries of a queue that the band sizes do not take into account, so that bands overflow and the in-stream fallback
+ * runs.  qd_scene_wavefront_info: the bands the NEXT width x height frame of this scene takes, and whether a band sized by
+ * the shader graph ever outgrew its queues (it was rendered again in form 0 on the spot, and the scene stays on form 0). */
 int qd_set_wavefront_budget(uint64_t queue_bytes, uint32_t max_entries);
 int qd_scene_wavefront_info(const qd_scene* scene, int width, int height, uint32_t* bands, int* overflowed);
 
