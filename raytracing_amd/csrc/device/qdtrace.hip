@@ -802,6 +802,7 @@ __global__ __launch_bounds__(64, FLAT ? kFlatWavesPerEU : QD_WAVES_PER_EU) void 
 }
 
 #include "wavefront.h"
+#include "wfsort_lab.h"
 
 // leaf_verts[ref] = tri_verts[leaf_tris[ref]] (9 doubles each): one pass at scene creation
 __global__ void gather_leaf_verts_kernel(const double* __restrict__ tri_verts, const uint32_t* __restrict__ leaf_tris,
@@ -1260,6 +1261,9 @@ int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hip
     const bool needs_calls = (s->geom_mask & kGeomCsgDeep) != 0 || s->nested_layered || s->small_mesh;
     const ShadeK sk = g_counting ? wf_shade_kernel<true, kGeomAll, true, true> : needs_calls ? wf_shade_kernel<false, kGeomAll, true, true>
                                  : (s->rich ? shade_rich : shade_plain)[s->geom_mask & 7];
+    const int lab = wf_sort_mode();
+    if (lab && !g_lab.e0) { HIP_TRY(hipEventCreate(&g_lab.e0)); HIP_TRY(hipEventCreate(&g_lab.e1)); }
+    if (lab) g_lab.frames++;
     const uint32_t max_blocks = s->n_lanes / 64;
     const uint32_t all_units = P.n_units, first_unit = P.unit0;
     const uint32_t band_units = (uint32_t)(plan.band_slots / kUnitPx);
@@ -1272,6 +1276,7 @@ int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hip
         HIP_TRY(hipMemsetAsync(w->wf_ctl + kWfTail, 0, kWfTailWords * sizeof(uint32_t), stream));
         P.stats = band_stats; P.user_stats = user_stats; P.cond = nullptr;
         for (uint32_t g = 0; g <= max_depth + 1; ++g) {
+            if (lab) HIP_TRY(hipEventRecord(g_lab.e0, stream));
             for (size_t k = 0; k < s->kd_node_list.size(); ++k) {
                 if (g_counting) hipLaunchKernelGGL(wf_walk_kernel<true>, dim3(grid0), dim3(64), 0, stream, s->d, P, (int)g, s->kd_node_list[k], (int)k);
                 else hipLaunchKernelGGL(wf_walk_kernel<false>, dim3(grid0), dim3(64), 0, stream, s->d, P, (int)g, s->kd_node_list[k], (int)k);
@@ -1279,6 +1284,19 @@ int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hip
             }
             hipLaunchKernelGGL(sk, dim3(grid0), dim3(64), 0, stream, s->d, P, (int)g);
             HIP_TRY(hipGetLastError());
+            if (lab) {                                                  // experiment (wfsort_lab.h): time the generation, order the next one
+                float ms = 0.f;
+                HIP_TRY(hipEventRecord(g_lab.e1, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (hipEventElapsedTime(&ms, g_lab.e0, g_lab.e1) == hipSuccess) g_lab.ms_trace += ms;
+                if (g <= max_depth) {
+                    HIP_TRY(hipEventRecord(g_lab.e0, stream));
+                    if (wf_lab_sort(P.wf_ray[(g + 1) & 1], (size_t)P.wf_cap, w->wf_ctl + (size_t)(g + 1) * kWfGenWords, P.wf_limit, stream)) return set_err("QD_WF_SORT: sort failed");
+                    HIP_TRY(hipEventRecord(g_lab.e1, stream));
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    if (hipEventElapsedTime(&ms, g_lab.e0, g_lab.e1) == hipSuccess) g_lab.ms_sort += ms;
+                }
+            }
         }
         hipLaunchKernelGGL(wf_band_end_kernel, dim3((unsigned)((band_slots + 63) / 64)), dim3(64), 0, stream, P);
         HIP_TRY(hipGetLastError());
@@ -1835,6 +1853,7 @@ extern "C" int qd_scene_create(const qd_scene_desc* desc, qd_scene** out) {
 
 extern "C" void qd_scene_destroy(qd_scene* s) {
     if (!s) return;
+    wf_lab_report();
     for (void* p : s->allocs) (void)hipFree(p);
     for (auto& w : s->sets) free_set(w);
     for (void* p : s->stg.p) if (p) (void)hipFree(p);
