@@ -177,6 +177,7 @@ def main():
                     help="'host': the exchange staged through host memory over gloo -- a rehearsal of N ranks sharing ONE GPU (RCCL refuses two ranks per device); not a measurement")
     ap.add_argument("--no-1080p", action="store_true", help="skip the 1920x1080 leg that follows a 3840x2160 run")
     ap.add_argument("--pipeline", type=int, default=None, help="qd_set_pipeline: 0 = one kernel with per-lane queues, 1 = wavefront, 2 = the faster of the two, measured (library default)")
+    ap.add_argument("--frame-parts", type=int, default=None, help="qd_set_frame_parts: concurrent parts of a lone wavefront frame (1 = off; default = library default, 4)")
     ap.add_argument("--kd-build", type=int, default=None, help="qd_set_kd_build: 1 = device tree by SAH from the triangles, 0 = the caller's planes + refined leaves")
     ap.add_argument("--kd-refine", default=None, help="'max_leaf,step_cost' for qd_set_kd_refine (tuning; default = library default)")
     args = ap.parse_args()
@@ -211,6 +212,8 @@ def main():
         device.set_pipeline(args.pipeline)
     if args.kd_build is not None:
         device.set_kd_build(args.kd_build)
+    if args.frame_parts is not None:
+        device.set_frame_parts(args.frame_parts)
     if args.kd_refine:
         ml, sc = args.kd_refine.split(",")
         device.set_kd_refine(int(ml), float(sc))
@@ -254,11 +257,13 @@ def main():
         device.set_pipeline(form)
     n_roof = max(3, min(args.steps, 10))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_roof)]
+    fr.render_shard()                        # (untimed: the first frame after frames in flight; the library treats the ones after it as a serial caller's)
+    torch.cuda.synchronize()
     for a, b in ev:
         a.record()
         fr.render_shard()
         b.record()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()             # every frame starts on a drained GPU: what a caller that renders one image gets
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / n_roof
 
     stats = fr.stats_dict()

@@ -99,7 +99,7 @@ class QdStats(C.Structure):
 
 # Every symbol include/qdtrace.h declares (checked by the CPU test-suite against the built library).
 QDTRACE_SYMBOLS = ["qd_init", "qd_set_counting", "qd_scene_check", "qd_scene_setup_info", "qd_scene_create", "qd_render", "qd_frame_begin", "qd_frame_read_rect", "qd_frame_end", "qd_antialias", "qd_antialias_device", "qd_aa_begin_device", "qd_aa_trace_part_async", "qd_aa_end_device", "qd_render_tiles_async", "qd_render_tiles_noalloc_async", "qd_scene_bind_stream", "qd_untile_async",
-                   "qd_quantize_bgr8_async", "qd_pack_rgb32_async", "qd_set_kd_refine", "qd_set_kd_build", "qd_set_pipeline", "qd_set_wavefront_budget", "qd_scene_wavefront_info", "qd_scene_schedule_info", "qd_scene_kd_info", "qd_scene_destroy", "qd_shutdown", "qd_last_error",
+                   "qd_quantize_bgr8_async", "qd_pack_rgb32_async", "qd_set_kd_refine", "qd_set_kd_build", "qd_set_pipeline", "qd_set_wavefront_budget", "qd_scene_wavefront_info", "qd_set_frame_parts", "qd_scene_frame_parts", "qd_scene_schedule_info", "qd_scene_kd_info", "qd_scene_destroy", "qd_shutdown", "qd_last_error",
                    "qd_comm_unique_id", "qd_comm_create", "qd_comm_destroy", "qd_comm_gather_async", "qd_comm_broadcast_async", "qd_gather_frame_async",
                    "qd_prep_heightfield", "qd_prep_highmap", "qd_prep_differentiate"]
 QDHOST_SYMBOLS = ["qdh_load_scene", "qdh_synth_scene", "qdh_scene_desc", "qdh_camera_corners", "qdh_bucket_list",

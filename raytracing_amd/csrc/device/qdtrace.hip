@@ -70,7 +70,8 @@ struct Params {
     int x0, y0, rw, rh;           // rectangle
     int tile, tiles_x, phase, stride;
     uint32_t n_units;             // 8x8 pixel units to render
-    uint32_t unit0;               // first unit of this launch (a frame rendered in bands: wavefront form, see launch_wavefront)
+    uint32_t unit0;               // first unit of this launch (a frame rendered in bands or parts: wavefront form, see launch_wavefront)
+    uint32_t unit_step;           // the launch's i-th unit is unit0 + i * unit_step (0 reads as 1; > 1: one of the interleaved parts of a lone frame)
     const uint32_t* cond;         // not null: the launch does nothing unless *cond != 0 (the in-stream fallback of a wavefront band)
     uint32_t units_x;             // rectangle mode: units per row
     uint32_t* queue_ctr;          // 8 work-queue counters, kCtlStride words apart (zeroed before launch)
@@ -503,6 +504,9 @@ QD_DEV void add_px(const Params& P, uint32_t pixel, const Col& c) {
 
 struct PixelSlot { int x, y; uint32_t out_idx; bool valid; uint32_t tap; };
 
+// the 8 x 8 unit that pixel slot `slot` of the launch lies in (see Params::unit0 / unit_step)
+QD_DEV uint32_t unit_of_slot(const Params& P, uint32_t slot) { return P.unit0 + (slot / kUnitPx) * (P.unit_step ? P.unit_step : 1u); }
+
 QD_DEV PixelSlot map_pixel(const Params& P, uint32_t unit, uint32_t p) {
     PixelSlot s;
     s.tap = 0;
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(64, FLAT ? kFlatWavesPerEU : QD_WAVES_PER_EU) void 
                 q.sp = 1;
             } else if (q.sp == 0 && rank < got) {
                 const uint32_t slot = first + rank;
-                const PixelSlot px = map_pixel(P, P.unit0 + slot / kUnitPx, slot % kUnitPx);
+                const PixelSlot px = map_pixel(P, unit_of_slot(P, slot), slot % kUnitPx);
                 if (px.valid) {
                     // Camera::GetScreenRay, src/camera.cpp:26-41 (integer pixel coordinates, no +0.5)
                     const DV TL = ld3(P.cam.top_left), TR = ld3(P.cam.top_right), BL = ld3(P.cam.bottom_left), pos = ld3(P.cam.position);
@@ -982,6 +986,7 @@ int set_err(const std::string& m) { g_err = m; return -1; }
 // rendered on different streams overlap on the GPU: the tail of one frame (few waves walking the last generations of
 // their ray trees) runs beside the start of the next.  Launches on one stream share a set and serialise as before.
 constexpr int kMaxWorkSets = 8;              // streams beyond the process's hardware queues (GPU_MAX_HW_QUEUES, 4 by default) share one and serialise
+constexpr uint32_t kMaxFrameParts = 4;
 constexpr int kErrAa = 8, kErrNoAlloc = 9, kErrFlags = 10;     // error words beyond the kMaxWorkSets per-set ones
 struct WorkSet {
     bool bound = false;
@@ -1083,6 +1088,11 @@ struct qd_scene {
     uint32_t* host_flag = nullptr;       // two pinned host words the device sets when a band of level 0 / 1 overflows (read without waiting), and their device address
     uint32_t* host_flag_dev = nullptr;
     int last_form = 0;                   // form of the most recent launch (qd_scene_schedule_info)
+    uint32_t last_parts = 1;             // concurrent parts the most recent launch was enqueued as (launch())
+    bool prev_overlapped = false;        // the most recent launch was enqueued while earlier work of the scene was still in flight
+    hipStream_t part_stream[kMaxFrameParts - 1] = {};   // the library's own streams and working sets for parts 1.. of a lone wavefront frame
+    WorkSet part_sets[kMaxFrameParts - 1];              // (apart from `sets`: callers' streams never take them over, and the other way round)
+    hipEvent_t part_fork = nullptr, part_join[kMaxFrameParts - 1] = {};
     uint64_t kd_nodes = 0, kd_refs = 0, kd_leaves = 0, kd_max_leaf = 0;   // device tree after refinement
     double t_kd_build = 0., t_upload = 0.;   // seconds of qd_scene_create spent building the device KD tree / uploading and gathering
 };
@@ -1122,11 +1132,8 @@ void free_set(WorkSet& w) {
 // The working set for a launch on `stream`, sized for max_depth: the set the stream used before, else a free one, else
 // the one used longest ago (the stream then waits for that set's last launch).  Allocates only when a set is new or
 // too small; qd_scene_bind_stream does this ahead of time.
+int size_set(qd_scene* s, WorkSet* w, hipStream_t stream, uint32_t max_depth);
 int acquire_set(qd_scene* s, hipStream_t stream, uint32_t max_depth, WorkSet** out) {
-    // LIFO bound: each processed task removes one slot and adds at most spawn tasks.
-    const uint64_t cap64 = (uint64_t)s->spawn0 + (uint64_t)s->spawn1 * max_depth + 2;
-    if (cap64 > 4096) return set_err("ray queue bound too large for this scene (samples x depth)");
-    const uint32_t cap = (uint32_t)cap64;
     WorkSet* w = nullptr;
     for (auto& c : s->sets) if (c.bound && c.stream == stream) { w = &c; break; }
     if (!w) for (auto& c : s->sets) if (!c.bound) { w = &c; break; }
@@ -1135,6 +1142,17 @@ int acquire_set(qd_scene* s, hipStream_t stream, uint32_t max_depth, WorkSet** o
         for (auto& c : s->sets) if (c.last_use < w->last_use) w = &c;
         HIP_TRY(hipStreamWaitEvent(stream, w->idle, 0));
     }
+    if (size_set(s, w, stream, max_depth)) return -1;
+    *out = w;
+    return 0;
+}
+
+// Binds `w` to `stream` and sizes its one-kernel queues for max_depth (allocates only when the set is new or too small).
+int size_set(qd_scene* s, WorkSet* w, hipStream_t stream, uint32_t max_depth) {
+    // LIFO bound: each processed task removes one slot and adds at most spawn tasks.
+    const uint64_t cap64 = (uint64_t)s->spawn0 + (uint64_t)s->spawn1 * max_depth + 2;
+    if (cap64 > 4096) return set_err("ray queue bound too large for this scene (samples x depth)");
+    const uint32_t cap = (uint32_t)cap64;
     w->bound = true; w->stream = stream; w->last_use = ++s->use_clock;
     if (!w->idle) HIP_TRY(hipEventCreateWithFlags(&w->idle, hipEventDisableTiming));
     if (!w->queue_ctr) HIP_TRY(hipMalloc((void**)&w->queue_ctr, (size_t)kPasses * kPassWords * sizeof(uint32_t)));
@@ -1148,7 +1166,6 @@ int acquire_set(qd_scene* s, hipStream_t stream, uint32_t max_depth, WorkSet** o
         }
         w->list_cap = (size_t)cap * s->n_lanes;
     }
-    *out = w;
     return 0;
 }
 
@@ -1179,10 +1196,10 @@ constexpr uint32_t kWfMaxGens = 67;          // generations a frame may have: ma
 //            generations and the same queues.  A band that overflows at this level takes the scene off the form.
 // An explicit qd_set_wavefront_budget is a hard limit: level 1 from the start.
 struct WfPlan { uint64_t cap; uint64_t band_slots; };
-WfPlan wavefront_plan(const qd_scene* s, uint64_t n_slots) {
+WfPlan wavefront_plan(const qd_scene* s, uint64_t n_slots, uint32_t share = 1) {      // share: the launch is one of `share` parts of a frame and gets that fraction of the budget
     const size_t n_kd = std::max<size_t>(1, s->kd_node_list.size());
     const uint64_t entry_bytes = 2ull * kEntryWords * 8 + (uint64_t)kWfResWords * 8 * n_kd;
-    const uint64_t budget = std::max<uint64_t>(kUnitPx * 4, std::min<uint64_t>(g_wf_budget / entry_bytes, (1ull << 31) - 1));
+    const uint64_t budget = std::max<uint64_t>(kUnitPx * 4, std::min<uint64_t>(g_wf_budget / std::max(1u, share) / entry_bytes, (1ull << 31) - 1));
     const uint64_t demand = std::max<uint64_t>(4, (uint64_t)s->spawn0 + 1);
     uint64_t want = n_slots * demand;
     // small launches (a bucket, a rectangle that lies on glass) get up to 32 entries per pixel while that stays below 8 M entries
@@ -1208,7 +1225,7 @@ constexpr size_t kWfTailWords = kCtlStride + 24 * 2;
 int reserve_wavefront(qd_scene* s, WorkSet* w, const Params& P, uint32_t max_depth) {
     if (max_depth + 3 > kWfMaxGens) return set_err("maxTraceDepth too large for the wavefront pipeline");
     const size_t n_kd = std::max<size_t>(1, s->kd_node_list.size());
-    const uint64_t cap64 = wavefront_plan(s, (uint64_t)P.n_units * kUnitPx).cap;
+    const uint64_t cap64 = wavefront_plan(s, (uint64_t)P.n_units * kUnitPx, P.unit_step).cap;
     // (no clearing here: a memset on the null stream is not ordered with the caller's stream and could land in the middle of the
     // frame; every band clears the words it uses on its own stream)
     if (!w->wf_ctl) HIP_TRY(hipMalloc((void**)&w->wf_ctl, (kWfTail + kWfTailWords) * sizeof(uint32_t)));
@@ -1231,19 +1248,21 @@ int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hi
 // the same band that returns at once unless the word is set (its per-lane queues are bounded by construction).  So the frame
 // is complete and correct either way, nothing comes back to the host and no call fails; a band that overflowed cost its time
 // twice, and the pinned host word keeps the scene on the one-kernel form from the next launch on.
-int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hipStream_t stream) {
+// err_owner: the working set whose error word the launch reports to (a part of a frame: the set of the caller's stream);
+// clear_frame: zero the output first (a part of a frame: launch() has done it once for all parts).
+int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hipStream_t stream, WorkSet* err_owner = nullptr, bool clear_frame = true) {
     if (reserve_wavefront(s, w, P, max_depth)) return -1;          // (a no-op when launch() has reserved already)
     const uint64_t n_slots = (uint64_t)P.n_units * kUnitPx;
-    const WfPlan plan = wavefront_plan(s, n_slots);
+    const WfPlan plan = wavefront_plan(s, n_slots, P.unit_step);
     P.wf_ray[0] = w->wf_ray[0]; P.wf_ray[1] = w->wf_ray[1]; P.wf_res = w->wf_res; P.wf_ctl = w->wf_ctl; P.wf_deep = w->wf_deep;
     P.wf_cap = (uint32_t)w->wf_cap;
     P.wf_limit = g_wf_max_entries ? std::min<uint32_t>(P.wf_cap, std::max<uint32_t>(g_wf_max_entries, 64u)) : P.wf_cap;
-    P.error_flag = s->error_flag + (w - s->sets);
+    P.error_flag = s->error_flag + ((err_owner ? err_owner : w) - s->sets);
     P.wf_over = w->wf_ctl + kWfTail;
     P.host_flag = s->host_flag_dev + (s->wf_level ? 1 : 0);           // which level's frame it was that overflowed
     unsigned long long* const band_stats = (unsigned long long*)(w->wf_ctl + kWfTail + kCtlStride);
     unsigned long long* const user_stats = P.stats;
-    HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));
+    if (clear_frame) HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));
     using ShadeK = void (*)(const DScene, const Params, int);
     // call-free copies by scene content (see wf_nodes); a scene that needs a call -- a mesh too small for a tree, a Layered
     // shader inside a layer, CSG over CSG / mesh / heightfield -- runs the one copy that holds everything
@@ -1265,10 +1284,10 @@ int launch_wavefront(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hip
     if (lab && !g_lab.e0) { HIP_TRY(hipEventCreate(&g_lab.e0)); HIP_TRY(hipEventCreate(&g_lab.e1)); }
     if (lab) g_lab.frames++;
     const uint32_t max_blocks = s->n_lanes / 64;
-    const uint32_t all_units = P.n_units, first_unit = P.unit0;
+    const uint32_t all_units = P.n_units, first_unit = P.unit0, step = P.unit_step ? P.unit_step : 1u;
     const uint32_t band_units = (uint32_t)(plan.band_slots / kUnitPx);
     for (uint32_t u = 0; u < all_units; u += band_units) {
-        P.unit0 = first_unit + u;
+        P.unit0 = first_unit + u * step;
         P.n_units = std::min(band_units, all_units - u);
         const uint64_t band_slots = (uint64_t)P.n_units * kUnitPx;
         const uint32_t grid0 = (uint32_t)std::min<uint64_t>(max_blocks, std::max<uint64_t>(1, (band_slots + 63) / 64));
@@ -1366,36 +1385,87 @@ int choose_form(qd_scene* s, uint64_t n_slots) {
     return best;
 }
 
+// A LONE frame of the wavefront form -- one enqueued while nothing else of the scene is in flight: what a caller that renders
+// one image, or waits for each frame, produces -- is enqueued as kMaxFrameParts concurrent PARTS: part k renders the 8 x 8
+// units k, k + 4, k + 8 ... on a stream and working set of its own (part 0 on the caller's), forked from and joined to the
+// caller's stream with events, so for the caller it is still one enqueue-only launch on its stream.  Why: a generation's walk
+// launch ends in a tail of a few long walks, its shade launch starts cold; with four sequences in flight one part's tails run
+// under another part's bulk, which is what frames in flight give a caller who has several frames (scripts/r03_split.py:
+// kdtree_test 10.0 -> 8.8 ms, lecture7 at 4K 8.1 -> 5.8 ms, kdtree_test at 4K 54.5 -> 42.8 ms).  The one-kernel form gains nothing
+// (12.97 -> 12.81 ms: its waves persist across the frame) and stays one launch sequence; frames that are not alone stay whole too.
+// So does the first frame of a burst that follows a burst: a caller who keeps F frames in flight gains nothing from parts (F
+// sequences already overlap) and would lose -- seven launch sequences side by side are slower than four (lecture7 at 4K: the
+// first four frames of a burst took 34 instead of 24 ms) -- so a frame is only split if the scene's previous frame was not
+// enqueued behind another one either (or there was none): the caller looks like one who waits for each frame.
+constexpr uint32_t kPartMinUnits = 12288;         // 1024 x 768 pixels: small frames are launch-bound and parts only add launches
+uint32_t g_frame_parts = kMaxFrameParts;          // qd_set_frame_parts
+
 int launch(qd_scene* s, Params& P, uint32_t max_depth, hipStream_t stream) {
     WorkSet* w = nullptr;
     if (acquire_set(s, stream, max_depth, &w)) return -1;
     read_sample(s, true);
-    read_overflow_words(s);     // a band outgrew its queues (and was rendered again in place)
+    read_overflow_words(s);                   // a band outgrew its queues (and was rendered again in place)?
     const int form = choose_form(s, (uint64_t)P.n_units * kUnitPx);
-    bool alone = g_pipeline == 2;                         // does this frame start on a drained GPU (as far as this scene goes)?
-    for (auto& c : s->sets) if (alone && c.t1 && hipEventQuery(c.t1) != hipSuccess) alone = false;
+    bool drained = true;                                  // does this frame start on a drained GPU (as far as this scene goes)?
+    for (auto& c : s->sets) if (drained && c.t1 && hipEventQuery(c.t1) != hipSuccess) drained = false;
+    const bool alone = drained && g_pipeline == 2;        // (only the adaptive choice takes samples)
     if (!w->t0) { HIP_TRY(hipEventCreate(&w->t0)); HIP_TRY(hipEventCreate(&w->t1)); }
     bool wavefront = form == 1 && s->kd_node_list.size() <= kWfMaxKdNodes;
-    if (wavefront && reserve_wavefront(s, w, P, max_depth)) {
+
+    // parts: their streams, working sets and queues first (nothing of this is timed)
+    uint32_t parts = 1;
+    WorkSet* pw[kMaxFrameParts] = {w, nullptr, nullptr, nullptr};
+    Params pp[kMaxFrameParts];
+    if (wavefront && drained && !s->prev_overlapped && g_frame_parts > 1 && P.n_units >= kPartMinUnits && P.unit_step <= 1u && !wf_sort_mode()) {
+        parts = std::min<uint32_t>(g_frame_parts, kMaxFrameParts);
+        if (!s->part_fork) HIP_TRY(hipEventCreateWithFlags(&s->part_fork, hipEventDisableTiming));
+        for (uint32_t k = 1; k < parts; ++k) {
+            if (!s->part_stream[k - 1]) HIP_TRY(hipStreamCreateWithFlags(&s->part_stream[k - 1], hipStreamNonBlocking));
+            if (!s->part_join[k - 1]) HIP_TRY(hipEventCreateWithFlags(&s->part_join[k - 1], hipEventDisableTiming));
+            pw[k] = &s->part_sets[k - 1];
+            if (size_set(s, pw[k], s->part_stream[k - 1], max_depth)) return -1;
+        }
+        // the caller's set keeps queues for a WHOLE frame (part 0 uses a fraction of them): its next frame may be enqueued behind
+        // others and stay whole, and growing the queues then would cost a device-wide wait in the middle of the caller's loop
+        if (reserve_wavefront(s, w, P, max_depth)) { (void)hipGetLastError(); parts = 1; }
+        for (uint32_t k = 0; k < parts && parts > 1; ++k) {
+            pp[k] = P;
+            pp[k].unit0 = P.unit0 + k; pp[k].unit_step = parts; pp[k].n_units = (P.n_units - k + parts - 1) / parts;
+            if (reserve_wavefront(s, pw[k], pp[k], max_depth)) { (void)hipGetLastError(); parts = 1; }   // no room: the frame stays whole
+        }
+    }
+    if (wavefront && parts == 1 && reserve_wavefront(s, w, P, max_depth)) {
         if (g_pipeline != 2) return -1;
         (void)hipGetLastError();                           // no room for its queues: the scene stays on the one-kernel form
         s->wavefront_overflowed = true; wavefront = false;
     }
     HIP_TRY(hipEventRecord(w->t0, stream));
-    const int rc = wavefront ? launch_wavefront(s, w, P, max_depth, stream)
-                                                                           : launch_one_kernel(s, w, P, max_depth, stream);
+    int rc = 0;
+    if (parts > 1) {
+        HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));
+        HIP_TRY(hipEventRecord(s->part_fork, stream));
+        for (uint32_t k = 1; k < parts; ++k) HIP_TRY(hipStreamWaitEvent(s->part_stream[k - 1], s->part_fork, 0));
+        for (uint32_t k = 0; k < parts && !rc; ++k)
+            rc = launch_wavefront(s, pw[k], pp[k], max_depth, k ? s->part_stream[k - 1] : stream, w, false);
+        for (uint32_t k = 1; k < parts; ++k) {             // (also after a failed enqueue: the caller's stream must not run ahead of what was enqueued)
+            if (hipEventRecord(s->part_join[k - 1], s->part_stream[k - 1]) != hipSuccess || hipStreamWaitEvent(stream, s->part_join[k - 1], 0) != hipSuccess)
+                return set_err("launch: joining the parts of a frame failed");
+        }
+    } else rc = wavefront ? launch_wavefront(s, w, P, max_depth, stream) : launch_one_kernel(s, w, P, max_depth, stream);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(w->t1, stream));
     s->sample.pending = alone;
     s->sample.form = wavefront ? 1 : 0; s->sample.slots = (uint64_t)P.n_units * kUnitPx; s->sample.t0 = w->t0; s->sample.t1 = w->t1;
     s->last_form = w->last_form = wavefront ? 1 : 0;
+    s->last_parts = parts;
+    s->prev_overlapped = !drained;
     return 0;
 }
 
 // fallback: the launch behind a wavefront band (P.cond set): one pass that runs to the end, the frame buffer is left alone
 int launch_one_kernel(qd_scene* s, WorkSet* w, Params& P, uint32_t max_depth, hipStream_t stream, bool fallback) {
     P.stack = w->stack; P.stack_cap = w->stack_cap; P.n_lanes = s->n_lanes;
-    P.error_flag = s->error_flag + (w - s->sets);
+    if (!fallback) P.error_flag = s->error_flag + (w - s->sets);      // (the fallback of a band reports where the band does)
     P.list_cap = w->list_cap;
     HIP_TRY(hipMemsetAsync(w->queue_ctr, 0, (size_t)(fallback ? 1 : kPasses) * kPassWords * sizeof(uint32_t), stream));
     if (!fallback) HIP_TRY(hipMemsetAsync(P.rgb, 0, P.rgb_floats * sizeof(float), stream));       // the kernel adds colours into it
@@ -1856,6 +1926,7 @@ extern "C" void qd_scene_destroy(qd_scene* s) {
     wf_lab_report();
     for (void* p : s->allocs) (void)hipFree(p);
     for (auto& w : s->sets) free_set(w);
+    for (auto& w : s->part_sets) free_set(w);
     for (void* p : s->stg.p) if (p) (void)hipFree(p);
     if (s->stg.host_frame) (void)hipHostFree(s->stg.host_frame);
     if (s->stg.e0) (void)hipEventDestroy(s->stg.e0);
@@ -1865,6 +1936,9 @@ extern "C" void qd_scene_destroy(qd_scene* s) {
     if (s->stats) (void)hipFree(s->stats);
     if (s->error_flag) (void)hipFree(s->error_flag);
     if (s->host_flag) (void)hipHostFree(s->host_flag);
+    for (auto& st : s->part_stream) if (st) (void)hipStreamDestroy(st);
+    for (auto& e : s->part_join) if (e) (void)hipEventDestroy(e);
+    if (s->part_fork) (void)hipEventDestroy(s->part_fork);
     delete s;
 }
 
@@ -2317,6 +2391,18 @@ extern "C" int qd_scene_check(qd_scene* s) {
 extern "C" int qd_set_wavefront_budget(uint64_t queue_bytes, uint32_t max_entries) {
     g_wf_budget = queue_bytes ? queue_bytes : kWfDefaultBudget;
     g_wf_max_entries = max_entries;
+    return 0;
+}
+
+extern "C" int qd_set_frame_parts(int parts) {
+    if (parts < 0 || parts > (int)kMaxFrameParts) return set_err("qd_set_frame_parts: 0 (default) or 1 .. 4");
+    g_frame_parts = parts ? (uint32_t)parts : kMaxFrameParts;
+    return 0;
+}
+
+extern "C" int qd_scene_frame_parts(const qd_scene* s, uint32_t* last_parts) {
+    if (!s) return set_err("qd_scene_frame_parts: null scene");
+    if (last_parts) *last_parts = s->last_parts;
     return 0;
 }
 

@@ -65,7 +65,7 @@ struct WfAppender {
 
 // The primary ray of pixel slot `slot` (Camera::GetScreenRay, src/camera.cpp:26-41); false for a slot outside the frame.
 QD_DEV bool wf_primary(const Params& P, uint32_t slot, Task& t) {
-    const PixelSlot px = map_pixel(P, P.unit0 + slot / kUnitPx, slot % kUnitPx);
+    const PixelSlot px = map_pixel(P, unit_of_slot(P, slot), slot % kUnitPx);
     if (!px.valid) return false;
     const DV TL = ld3(P.cam.top_left), TR = ld3(P.cam.top_right), BL = ld3(P.cam.bottom_left), pos = ld3(P.cam.position);
     const double kx = (px.tap == 1u || px.tap == 4u) ? 0.6 : (px.tap == 3u ? 0.3 : 0.0);      // anti-aliasing taps, src/main.cpp:108-114
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64) void wf_band_end_kernel(const Params P) {
     if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(P.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
     if (slot >= P.n_units * kUnitPx) return;
-    const PixelSlot px = map_pixel(P, P.unit0 + slot / kUnitPx, slot % kUnitPx);
+    const PixelSlot px = map_pixel(P, unit_of_slot(P, slot), slot % kUnitPx);
     if (!px.valid) return;
     float* o = P.rgb + (P.mode == 0 ? (size_t)(px.out_idx / (uint32_t)P.rw) * P.pitch + (size_t)(px.out_idx % (uint32_t)P.rw) * 3 : (size_t)px.out_idx * 3);
     o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;

@@ -68,6 +68,8 @@ def lib():
         L.qd_set_kd_build.argtypes = [C.c_int]
         L.qd_set_wavefront_budget.argtypes = [C.c_uint64, C.c_uint32]
         L.qd_scene_wavefront_info.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_uint32), P(C.c_int)]
+        L.qd_set_frame_parts.argtypes = [C.c_int]
+        L.qd_scene_frame_parts.argtypes = [C.c_void_p, P(C.c_uint32)]
         L.qd_scene_schedule_info.argtypes = [C.c_void_p, P(C.c_int), P(C.c_double), P(C.c_double)]
         L.qd_prep_heightfield.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.qd_prep_highmap.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
@@ -129,6 +131,11 @@ def set_wavefront_budget(queue_bytes=0, max_entries=0):
     """Bytes the ray queues of the wavefront form may take per working set (0 = 16 GB: frames beyond it are rendered in bands)
     and, for tests, a cap on a queue's entries that the band sizes ignore (bands then overflow and are rendered again in place)."""
     _check(lib().qd_set_wavefront_budget(queue_bytes, max_entries), "qd_set_wavefront_budget")
+
+
+def set_frame_parts(parts=0):
+    """qd_set_frame_parts: concurrent parts a lone wavefront frame is enqueued as (0 = default 4, 1 = off)."""
+    _check(lib().qd_set_frame_parts(parts), "qd_set_frame_parts")
 
 
 def set_kd_refine(max_leaf_tris=2, step_cost=0.6):
@@ -290,6 +297,12 @@ class DeviceScene:
         f, a, b = C.c_int(), C.c_double(), C.c_double()
         _check(lib().qd_scene_schedule_info(self._h, C.byref(f), C.byref(a), C.byref(b)), "qd_scene_schedule_info")
         return {"form": int(f.value), "ns_per_pixel": [float(a.value), float(b.value)]}
+
+    def frame_parts(self):
+        """Concurrent parts the scene's latest launch was enqueued as (qd_scene_frame_parts)."""
+        n = C.c_uint32(0)
+        _check(lib().qd_scene_frame_parts(self._h, C.byref(n)), "qd_scene_frame_parts")
+        return int(n.value)
 
     def wavefront_info(self, width=None, height=None):
         """Bands a frame of this size takes in the wavefront form, and whether a band ever outgrew its queues."""

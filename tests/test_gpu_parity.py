@@ -754,6 +754,74 @@ def test_frame_begun_ahead_survives_an_overflow_and_a_render_in_between(load_sce
         _aa_settings(s, **old)
 
 
+def test_lone_wavefront_frame_is_enqueued_in_parts(load_scene):
+    """A frame of the wavefront form that starts on a drained scene is enqueued as four concurrent parts (8 x 8 units k,
+    k + 4, ... each on a stream and working set of the library's own; qd_set_frame_parts): same frame, hit planes and
+    ray counts as the whole-frame launch and as the one-kernel form.  A frame enqueued while another one is in flight stays
+    whole; so do the frame after it, small frames and the one-kernel form.  With queues that every band outgrows, every part takes its in-stream
+    fallback and the frame is still complete."""
+    import torch
+    s = load_scene("kdtree_fixed.qdmg")
+    old = _aa_settings(s, want_aa=0)
+    W, H = s.settings.frame_width, s.settings.frame_height
+    try:
+        ds = device.DeviceScene(s)
+        try:
+            device.set_pipeline(0)
+            ref, href, sref = ds.render(hits=True)
+            assert ds.frame_parts() == 1
+            device.set_pipeline(1)
+            device.set_frame_parts(1)
+            whole, hwhole, swhole = ds.render(hits=True)
+            assert ds.frame_parts() == 1
+            device.set_frame_parts(0)
+            for _ in range(2):                                   # twice: the parts' streams and sets are reused
+                a, ha, sa = ds.render(hits=True)
+                assert ds.frame_parts() == 4 and ds.schedule_info()["form"] == 1
+                for k in ("rays", "primary_rays", "shadow_rays", "depth_killed"):
+                    assert sa[k] == sref[k] == swhole[k], k
+                assert np.abs(a - ref).max() <= COLOUR_TOL and np.abs(a - whole).max() <= COLOUR_TOL
+                for x, y in zip(ha[:2], href[:2]):
+                    assert (x == y).all()
+                assert (ha[2].view(np.int64) == href[2].view(np.int64)).all()
+            part, _, pst = ds.render(560, 400, 688, 496)         # a small rectangle stays whole
+            assert ds.frame_parts() == 1 and np.abs(part - ref[400:496, 560:688]).max() <= COLOUR_TOL
+            # asynchronous frames: the first starts alone (parts), the second is enqueued behind it (whole)
+            tile, dev = 32, torch.device("cuda:0")
+            from raytracing_amd import sharding
+            tpr = sharding.tiles_per_rank_padded(W, H, tile, 1)
+            bufs = [torch.zeros((tpr, tile, tile, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+            frames = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+            streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            torch.cuda.synchronize()
+            seen = []
+            for k in range(2):
+                ds.render_tiles_async(bufs[k].data_ptr(), tile, 0, 1, stream=streams[k].cuda_stream)
+                seen.append(ds.frame_parts())
+                device.untile_async(bufs[k].data_ptr(), frames[k].data_ptr(), W, H, tile, 1, tpr, stream=streams[k].cuda_stream)
+            torch.cuda.synchronize()
+            ds.check()
+            assert seen == [4, 1], seen
+            for f in frames:
+                assert np.abs(f.cpu().numpy() - ref).max() <= COLOUR_TOL
+            ds.render()                                          # the first frame after one that was enqueued behind another stays whole
+            assert ds.frame_parts() == 1                         # (a caller with frames in flight gains nothing from parts)
+            # every part overflows (the test switch): four fallbacks side by side
+            device.set_wavefront_budget(0, 20000)
+            b, _, sb = ds.render()
+            ds.check()
+            assert ds.frame_parts() == 4
+            assert sb["rays"] == sref["rays"] and sb["shadow_rays"] == sref["shadow_rays"]
+            assert np.abs(b - ref).max() <= COLOUR_TOL
+        finally:
+            ds.close()
+    finally:
+        device.set_pipeline(2)
+        device.set_frame_parts(0)
+        device.set_wavefront_budget(0, 0)
+        _aa_settings(s, **old)
+
+
 def test_adaptive_choice_times_both_forms_and_reports_setup(load_scene):
     """qd_set_pipeline(2): after FrameRenderer.settle() both scheduling forms have a measured ns-per-pixel figure (lone
     frames, two per form); the frames that follow -- in flight, untimed -- run in the faster one (kdtree_fixed: the forms
