@@ -265,6 +265,7 @@ def main():
         b.record()
         torch.cuda.synchronize()             # every frame starts on a drained GPU: what a caller that renders one image gets
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / n_roof
+    lone_parts = fr.dscene.frame_parts()     # a lone frame of the wavefront form is enqueued as concurrent parts (qd_set_frame_parts)
 
     stats = fr.stats_dict()
     rays_local = torch.tensor([stats["rays"], stats["primary_rays"], stats["shadow_rays"]], dtype=torch.float64)
@@ -292,7 +293,7 @@ def main():
 
     if rank == 0:
         n_kd = sum(1 for i in range(scene.desc.n_nodes) if scene.desc.geoms[scene.desc.nodes[i].geom].type == 5 and (scene.desc.meshes[scene.desc.geoms[scene.desc.nodes[i].geom].a].kd_root >= 0 or scene.desc.meshes[scene.desc.geoms[scene.desc.nodes[i].geom].a].flags & 4))
-        launches = 3 if form == 0 else (scene.settings.max_trace_depth + 2) * (n_kd + 1)
+        launches = 3 if form == 0 else (scene.settings.max_trace_depth + 2) * (n_kd + 1) * lone_parts
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         ms_step = elapsed / args.steps * 1e3
         achieved_in_flight = alg_bytes / (ms_step * 1e-3) / 1e9         # the same bytes over what a frame costs with F frames in flight
@@ -327,9 +328,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "frac_lone": achieved / HBM_PEAK_GBS, "frac_in_flight": achieved_in_flight / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "other_bounds": other,
                          "kernel": "trace_kernel" if form == 0 else "wf_walk_kernel + wf_shade_kernel", "kernel_ms": kernel_ms,
-                         "launches_per_step": launches, "launch_avg_ms": kernel_ms / launches,
+                         "launches_per_step": launches, "launch_avg_ms": kernel_ms / launches, "lone_frame_parts": lone_parts,
                          "note": ("one frame = 3 launches of trace_kernel (pixels, then two passes over handed-over ray tasks, usually empty)" if form == 0 else
-                                  "one frame = (maxTraceDepth + 2) x (one wf_walk_kernel launch per KD-mesh node + one wf_shade_kernel launch)") +
+                                  "one frame = (maxTraceDepth + 2) x (one wf_walk_kernel launch per KD-mesh node + one wf_shade_kernel launch)"
+                                  + (f", a lone frame as {lone_parts} concurrent parts on streams of the scene's own (kernel_ms is the frame's span on the caller's stream; the parts' launches overlap, so their durations in a rocprofv3 trace sum to more)" if lone_parts > 1 else "")) +
                                  "; kernel_ms, achieved, frac (= frac_lone) and traffic are per frame = the sum over its launches, measured on frames that run alone (a separate untimed loop after the timed region; rocprofv3 of `bench.py --frames-in-flight 1`: TotalDurationNs / frames); the timed region overlaps frames, so ms_per_step can be below kernel_ms: frac_in_flight prices the same bytes on ms_per_step",
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_visit_and_test": [per_visit, per_test],
                          "kd_nodes_visited": cstats["kd_nodes_visited"], "tris_tested": cstats["tris_tested"]},

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r03_ab; mkdir -p "$OUT"
 VARS=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do VARS+=("$1"); shift; done; [ $# -gt 0 ] && shift
 for v in "${VARS[@]}"; do
-  timeout -k 10 240 python scripts/ab_bench.py build_variants/libqdtrace_$v.so --steps 40 --no-1080p "$@" > "$OUT/$v.json" 2> "$OUT/$v.err" || { echo "$v FAILED"; tail -5 "$OUT/$v.err"; continue; }
+  timeout -k 10 240 python scripts/ab_bench.py build_variants/libqdtrace_$v.so --steps 40 --no-1080p "$@" > "$OUT/$v.json" 2> "$OUT/$v.err" || { echo "$v FAILED"; tail -5 "$OUT/$v.err"; exit 1; }
   python - "$OUT/$v.json" "$v" <<'P'
 import json,sys
 d=json.load(open(sys.argv[1])); r=d["roofline"]; p=d.get("parity") or {}
