@@ -97,6 +97,7 @@ def cpu_baseline(scene, budget_s=12.0, gpu_frame=None):
         idx = np.arange(0, W * H, step, dtype=np.int64)[:n]
         return np.stack([idx % W, idx // W], 1).astype(np.int32)
 
+    scene.ensure_kd()              # the reference-shaped tree the oracle walks is built on request (2 s for 10 M triangles): not part of the timing
     xy = sample(4096)
     t = time.perf_counter(); _, _, st = oracle.render_pixels(scene, xy, rng_mode=1, threads=1); dt = time.perf_counter() - t
     n = int(min(W * H, max(4096, 4096 * budget_s / max(dt, 1e-3))))
