@@ -822,6 +822,37 @@ def test_lone_wavefront_frame_is_enqueued_in_parts(load_scene):
         _aa_settings(s, **old)
 
 
+def test_aa_pass_of_a_large_frame_in_parts(load_scene):
+    """The AA pass of a frame whose list of marked pixels is long enough for frame parts (non-adaptive AA marks every pixel:
+    1.08 M pixels x 4 taps = 67 500 units of 64 samples): first pass and tap pass are each enqueued as four concurrent parts
+    in the wavefront form; the frame and the ray counts are those of whole launches."""
+    s = load_scene("kdtree_fixed.qdmg")
+    old = _aa_settings(s, want_aa=1, want_adaptive_aa=0, show_aa=0)
+    try:
+        device.set_pipeline(1)
+        out = {}
+        for parts in (1, 0):
+            device.set_frame_parts(parts)
+            ds = device.DeviceScene(s)
+            try:
+                first, _, _ = ds.render()
+                frame = first.copy()
+                aa = ds.antialias(frame)
+                out[parts] = (frame, aa, ds.frame_parts())
+                ds.check()
+            finally:
+                ds.close()
+        assert out[1][2] == 1 and out[0][2] == 4                       # the tap pass itself ran whole / in parts
+        assert np.abs(out[0][0] - out[1][0]).max() <= SUM_ORDER_TOL
+        for k in ("rays", "primary_rays", "shadow_rays", "depth_killed"):
+            assert out[0][1][k] == out[1][1][k], k
+        assert out[0][1]["primary_rays"] == 4 * 1200 * 900
+    finally:
+        device.set_pipeline(2)
+        device.set_frame_parts(0)
+        _aa_settings(s, **old)
+
+
 def test_adaptive_choice_times_both_forms_and_reports_setup(load_scene):
     """qd_set_pipeline(2): after FrameRenderer.settle() both scheduling forms have a measured ns-per-pixel figure (lone
     frames, two per form); the frames that follow -- in flight, untimed -- run in the faster one (kdtree_fixed: the forms
