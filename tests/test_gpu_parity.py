@@ -644,6 +644,45 @@ def test_wavefront_form_renders_a_big_glossy_frame_in_bands(load_scene):
         st.frame_width, st.frame_height, st.want_aa = old
 
 
+def test_big_glossy_frames_in_flight_outgrow_their_first_queues(load_scene):
+    """The same 4K glossy scene through the asynchronous entry point with two frames in flight on a fresh handle: the first frame
+    starts alone and is enqueued in four parts, the second whole, both with the optimistic queues of a scene's first frames,
+    which they outgrow -- every part and the whole frame take the in-stream fallback, on their own streams, side by side.  All
+    frames equal the one-kernel form's; afterwards the scene renders in bands and is still eligible for the form."""
+    from raytracing_amd import renderer
+    s = load_scene("hw9/dragon.qdmg")
+    st = s.settings
+    old = (st.frame_width, st.frame_height, st.want_aa)
+    st.frame_width, st.frame_height, st.want_aa = 3840, 2160, 0
+    try:
+        device.set_pipeline(0)
+        ds = device.DeviceScene(s)
+        try:
+            ref, _, _ = ds.render()
+        finally:
+            ds.close()
+        device.set_pipeline(1)
+        fr = renderer.FrameRenderer(s, tile=32, rank=0, world=1, local_device=0, frames_in_flight=2)
+        try:
+            assert fr.dscene.wavefront_info()["bands"] == 1
+            slots = [fr.submit_frame() for _ in range(2)]
+            frames = [fr.wait(k).cpu().numpy() for k in slots]
+            fr.check()
+            for f in frames:
+                assert np.abs(f - ref).max() <= COLOUR_TOL
+            info = fr.dscene.wavefront_info()
+            assert info["bands"] >= 2 and not info["overflowed"]
+            k = fr.submit_frame()                                # sized by the shader graph now: bands (inside four parts), no overflow
+            assert np.abs(fr.wait(k).cpu().numpy() - ref).max() <= COLOUR_TOL
+            fr.check()
+            assert not fr.dscene.wavefront_info()["overflowed"] and fr.dscene.schedule_info()["form"] == 1
+        finally:
+            fr.close()
+    finally:
+        device.set_pipeline(2)
+        st.frame_width, st.frame_height, st.want_aa = old
+
+
 @pytest.mark.parametrize("name", ["kdtree_fixed.qdmg", "lecture7_fixed.qdmg"])
 def test_wavefront_queues_cannot_fail_a_call(load_scene, name):
     """No call fails over the wavefront queues.  With the queues cut to 20 000 entries (qd_set_wavefront_budget's test switch;
